@@ -1,0 +1,164 @@
+/*
+ * pch_hip.h -- C ABI of libpch_hip.so: the MI355X (gfx950) implementation of the
+ * pointcloudhookup ground-removal + tower-clustering hot path.
+ *
+ * The reference (Daniel-Starr/pointcloudhookup) is pure Python; the arithmetic of its
+ * hot path lives in library calls (Open3D, numpy, scikit-learn).  Every entry point
+ * below replaces exactly one of those call sites (cited as reference file:line), so the
+ * reference's Python modules can bind them with ctypes.
+ *
+ * Conventions
+ *  - plain C: pointers, sizes, scalars.  No torch/HIP types in signatures
+ *    (`stream` is a hipStream_t passed as void*; NULL = default stream).
+ *  - every `const T*` / `T*` argument is a DEVICE pointer unless its name ends in
+ *    `_host`.  Buffers are caller-owned.
+ *  - return value: 0 = ok, <0 = PCH_ERR_*.  pch_last_error() gives a thread-local text.
+ *  - the library never allocates device memory: scratch is a caller-provided workspace
+ *    whose size comes from the matching *_ws_bytes() (a pure host function).
+ *  - entry points enqueue work on `stream` and return without synchronising, except the
+ *    ones documented "synchronises" (they must read a device-side count to size the next
+ *    launch).
+ *  - results are bit-exact restatements of the reference's arithmetic: the library is
+ *    built with -ffp-contract=off; float64 division is IEEE.
+ */
+#ifndef PCH_HIP_H
+#define PCH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCH_VERSION 100
+
+#define PCH_OK               0
+#define PCH_ERR_ARG         -1   /* bad argument (null pointer, negative size, eps<=0 ...) */
+#define PCH_ERR_WORKSPACE   -2   /* workspace too small */
+#define PCH_ERR_HIP         -3   /* a HIP runtime call failed */
+#define PCH_ERR_RANGE       -4   /* grid does not fit the 64-bit cell/voxel key */
+#define PCH_ERR_NODEVICE    -5   /* no gfx950 device visible */
+
+int         pch_version(void);
+const char* pch_last_error(void);
+/* number of visible HIP devices (0 if none); does not initialise a context */
+int         pch_device_count(void);
+
+/* ------------------------------------------------------------------ stage A
+ * Open3D PointCloud.voxel_down_sample applied per file-order chunk.
+ * Replaces: ui/import_PC.py:8-13 (process_chunk) inside the loop ui/import_PC.py:45-58
+ *           (twin: ui/Sampling.py:10-18,46-60).
+ * xyz        [n,3] float64, row-major
+ * chunk_size points per chunk (<=0: one chunk); every chunk has its own grid origin
+ *            min(chunk) - voxel/2; duplicates across chunks are kept (as the reference).
+ * out_idx    [n,3] int32   voxel index triplets   } capacity n rows, the first *out_m rows
+ * out_mean   [n,3] float64 sum(points in order)/count } are valid; rows are grouped by chunk
+ * out_count  [n]   int32                           } and sorted by (ix,iy,iz) inside a chunk
+ * out_chunk_offsets [nchunks+1] int64 (may be NULL): slice of each chunk in the output
+ * out_m      [1] int64 number of voxels
+ */
+size_t pch_voxel_downsample_ws_bytes(int64_t n, int64_t chunk_size);
+int pch_voxel_downsample_f64(const double* xyz, int64_t n, double voxel_size,
+                             int64_t chunk_size,
+                             int32_t* out_idx, double* out_mean, int32_t* out_count,
+                             int64_t* out_chunk_offsets, int64_t* out_m,
+                             void* ws, size_t ws_bytes, void* stream);
+
+/* laspy scaled view, stage A0: out = (double)X * scale + offset (no FMA).
+ * Replaces: the chunk.x/.y/.z reads at ui/import_PC.py:47-48 and las.x/.y/.z at
+ *           utils/tower_extraction.py:62.  XYZ [n,3] int32 (LAS record ints, AoS). */
+int pch_las_scale_i32_f64(const int32_t* XYZ, int64_t n, const double* scale3_host,
+                          const double* offset3_host, double* out_xyz, void* stream);
+/* laspy coordinate setter, stage A3: out = (int32) rint((v - offset) / scale).
+ * Replaces: downsampled.x/.y/.z = ... at ui/import_PC.py:61-63 and
+ *           utils/tower_extraction.py:254-256. */
+int pch_las_unscale_f64_i32(const double* xyz, int64_t n, const double* scale3_host,
+                            const double* offset3_host, int32_t* out_XYZ, void* stream);
+
+/* ------------------------------------------------------------------ stage B
+ * .astype(np.float32) of utils/tower_extraction.py:62 */
+int pch_cast_f64_f32(const double* in, int64_t count, float* out, void* stream);
+
+/* np.mean(raw_points, axis=0) for a C-order [n,3] float32 array, bit-exact: a
+ * SEQUENTIAL float32 running sum per column divided by float32(n).
+ * Replaces: utils/tower_extraction.py:63.   out_centroid [3] float32. */
+size_t pch_mean_seq_f32_ws_bytes(int64_t n);
+int pch_mean_seq_f32(const float* xyz, int64_t n, float* out_centroid,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* np.percentile(v, q) (method 'linear', numpy 2.x float32 semantics) of the strided
+ * float32 column v[i] = base[i*stride] - (sub ? *sub : 0).
+ * Replaces: utils/tower_extraction.py:82-83 (z_values = points[:,2]; percentile 25).
+ * out [1] float32. */
+size_t pch_percentile_f32_ws_bytes(int64_t n);
+int pch_percentile_f32(const float* base, int64_t n, int64_t stride, const float* sub,
+                       double q_percent, float* out,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* Fused stage B: centroid, centring, percentile threshold, order-preserving compaction.
+ * Replaces: utils/tower_extraction.py:63-64,82-89
+ *   centroid = mean(raw); points = raw - centroid; base = percentile(points[:,2], pct);
+ *   keep = z > base + offset; if kept < min_keep: keep = z > base + fallback_offset.
+ * raw          [n,3] float32
+ * out_points   [n,3] float32 capacity; first *out_count rows = points[keep] (file order)
+ * out_index    [n]   int32 (may be NULL): original row of each kept point
+ * out_scalars  [8]   float32: centroid xyz, base, threshold, used_fallback(0/1), 0, 0
+ * out_count    [1]   int64
+ * out_aabb     [6]   float32 (may be NULL): min xyz, max xyz of the kept points
+ */
+size_t pch_ground_filter_ws_bytes(int64_t n);
+int pch_ground_filter_f32(const float* raw, int64_t n, double pct, float offset,
+                          float fallback_offset, int64_t min_keep,
+                          float* out_points, int32_t* out_index, float* out_scalars,
+                          int64_t* out_count, float* out_aabb,
+                          void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ stage C
+ * sklearn.cluster.DBSCAN(eps, min_samples, algorithm='ball_tree').fit(chunk).labels_ for
+ * every consecutive chunk_size-row chunk, with the reference's label offsetting.
+ * Replaces: the loop utils/tower_extraction.py:96-117.
+ * xyz        [n,3] float32 (n known on the host)
+ * chunk_size rows per fit (reference: 50000); <=0: one global fit
+ * labels     [n] int32: -1 noise, else cluster id, ids dense and ordered exactly as the
+ *            reference's all_labels
+ * core       [n] uint8 (may be NULL): 1 for core samples
+ * out_nclusters [1] int32
+ * Exact rule implemented (equals sklearn's sweep): neighbours are
+ * sum_j((double)x_j-(double)y_j)^2 <= eps*eps; core = >= min_samples neighbours incl.
+ * self; clusters = components of the core graph numbered by smallest core index;
+ * border point -> smallest cluster id among its core neighbours.
+ * Synchronises once (reads the bounding box to size the cell grid) unless aabb_host
+ * (min xyz, max xyz of the input, any superset box) is given.
+ */
+size_t pch_dbscan_ws_bytes(int64_t n);
+int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t min_samples,
+                   int64_t chunk_size, const float* aabb_host,
+                   int32_t* labels, uint8_t* core, int32_t* out_nclusters,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ stage D0
+ * Groups points by cluster label in one pass instead of the reference's K boolean
+ * masks.  Replaces: utils/tower_extraction.py:125,131-134.
+ * labels [n] int32 in [-1, nclusters)
+ * out_perm    [n] int32: point rows ordered by (label, row); noise rows last
+ * out_offsets [nclusters+1] int64: cluster k owns out_perm[offsets[k]:offsets[k+1]]
+ * out_stats   [nclusters,8] float32 (may be NULL): min xyz, max xyz, 0, 0 per cluster
+ */
+size_t pch_segment_by_label_ws_bytes(int64_t n, int32_t nclusters);
+int pch_segment_by_label(const int32_t* labels, const float* xyz, int64_t n,
+                         int32_t nclusters, int32_t* out_perm, int64_t* out_offsets,
+                         float* out_stats, void* ws, size_t ws_bytes, void* stream);
+
+/* --------------------------------------------------------- profiling helpers
+ * Last-call timings recorded with hipEvents on the caller's stream when
+ * pch_set_profiling(1): fills up to `cap` (name, total ms, launch count) triples for the
+ * kernels of the last pch_* call made by this thread.  Returns the number of entries.
+ * (synchronises) */
+void pch_set_profiling(int enable);
+int  pch_get_profile(int cap, char names[][48], float* ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCH_HIP_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of libpch_hip.so (C ABI declared in include/pch_hip.h).
+
+The product path has no CPU fallback: if the library is missing or fails to load this
+module raises, loudly.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C pointcloudhookup_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpch_hip.so")
+
+PCH_OK = 0
+ERR_NAMES = {-1: "PCH_ERR_ARG", -2: "PCH_ERR_WORKSPACE", -3: "PCH_ERR_HIP",
+             -4: "PCH_ERR_RANGE", -5: "PCH_ERR_NODEVICE"}
+
+
+class PchError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+_vp, _i64, _i32, _f64, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_float, C.c_size_t
+
+_SIGS = {
+    "pch_version": (C.c_int, []),
+    "pch_last_error": (C.c_char_p, []),
+    "pch_device_count": (C.c_int, []),
+    "pch_voxel_downsample_ws_bytes": (_sz, [_i64, _i64]),
+    "pch_voxel_downsample_f64": (C.c_int, [_vp, _i64, _f64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pch_las_scale_i32_f64": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "pch_las_unscale_f64_i32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "pch_cast_f64_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "pch_mean_seq_f32_ws_bytes": (_sz, [_i64]),
+    "pch_mean_seq_f32": (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "pch_percentile_f32_ws_bytes": (_sz, [_i64]),
+    "pch_percentile_f32": (C.c_int, [_vp, _i64, _i64, _vp, _f64, _vp, _vp, _sz, _vp]),
+    "pch_ground_filter_ws_bytes": (_sz, [_i64]),
+    "pch_ground_filter_f32": (C.c_int, [_vp, _i64, _f64, _f32, _f32, _i64, _vp, _vp, _vp, _vp, _vp,
+                                        _vp, _sz, _vp]),
+    "pch_dbscan_ws_bytes": (_sz, [_i64]),
+    "pch_dbscan_f32": (C.c_int, [_vp, _i64, _f64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pch_segment_by_label_ws_bytes": (_sz, [_i64, _i32]),
+    "pch_segment_by_label": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pch_set_profiling": (None, [C.c_int]),
+    "pch_get_profile": (C.c_int, [C.c_int, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Every symbol include/pch_hip.h declares (used by the CPU symbol test)."""
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found - the HIP extension is not built. There is no CPU "
+                "fallback; run `make -C pointcloudhookup_amd/csrc` (needs hipcc).")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)          # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != PCH_OK:
+        raise PchError(rc, lib().pch_last_error().decode("utf-8", "replace"))
+
+
+def get_profile(cap=128):
+    """[(kernel name, total ms, launches)] of the last pch_* call of this thread."""
+    names = (C.c_char * 48 * cap)()
+    ms = (C.c_float * cap)()
+    cnt = (C.c_int * cap)()
+    n = lib().pch_get_profile(cap, C.cast(names, _vp), C.cast(ms, _vp), C.cast(cnt, _vp))
+    return [(names[i].value.decode(), float(ms[i]), int(cnt[i])) for i in range(n)]

@@ -1,0 +1,146 @@
+// Shared host/device helpers for libpch_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/pch_hip.h"
+
+namespace pch {
+
+// ---------------------------------------------------------------- errors
+void set_error(const char* fmt, ...);
+
+#define PCH_HIP_TRY(expr)                                                         \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) {                                                   \
+            ::pch::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                             __FILE__, __LINE__);                                 \
+            return PCH_ERR_HIP;                                                   \
+        }                                                                         \
+    } while (0)
+
+#define PCH_TRY(expr)                  \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != PCH_OK) return _rc; \
+    } while (0)
+
+#define PCH_REQUIRE(cond, msg)                                   \
+    do {                                                         \
+        if (!(cond)) {                                           \
+            ::pch::set_error("%s: %s", __func__, msg);           \
+            return PCH_ERR_ARG;                                  \
+        }                                                        \
+    } while (0)
+
+// ---------------------------------------------------------------- workspace arena
+// The same plan function is run once with base == nullptr (size query) and once with the
+// caller's buffer, so *_ws_bytes() can never disagree with the real carve-up.
+struct Arena {
+    char*  base;
+    size_t cap;
+    size_t off;
+    bool   overflow;
+    explicit Arena(void* b = nullptr, size_t c = 0)
+        : base(static_cast<char*>(b)), cap(c), off(0), overflow(false) {}
+    template <typename T>
+    T* take(size_t count) {
+        size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
+        size_t at = off;
+        off += bytes;
+        if (!base) return nullptr;
+        if (off > cap) { overflow = true; return nullptr; }
+        return reinterpret_cast<T*>(base + at);
+    }
+    size_t mark() const { return off; }
+    void   reset(size_t m) { off = m; }
+};
+
+// ---------------------------------------------------------------- profiling
+// When enabled every PCH_LAUNCH is bracketed by hipEvents recorded on the launch stream.
+void prof_begin_call();                       // clears this thread's record list
+bool prof_enabled();
+void prof_pre(const char* name, hipStream_t s);
+void prof_post(hipStream_t s);
+
+#define PCH_LAUNCH(name, kernel, grid, block, shmem, stream, ...)                  \
+    do {                                                                           \
+        if (::pch::prof_enabled()) ::pch::prof_pre(name, stream);                  \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);       \
+        if (::pch::prof_enabled()) ::pch::prof_post(stream);                       \
+        hipError_t _le = hipGetLastError();                                        \
+        if (_le != hipSuccess) {                                                   \
+            ::pch::set_error("launch %s failed: %s", name, hipGetErrorString(_le)); \
+            return PCH_ERR_HIP;                                                    \
+        }                                                                          \
+    } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int bits_for(uint64_t count) {   // bits needed to store values in [0, count)
+    int b = 0;
+    while (b < 64 && (uint64_t(1) << b) < count) ++b;
+    return b;
+}
+
+// ---------------------------------------------------------------- device helpers
+#ifdef __HIPCC__
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// order-preserving float <-> uint transforms (for atomicMin/Max and radix select)
+__device__ __forceinline__ uint32_t f32_ordered(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_unordered(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ uint64_t f64_ordered(double d) {
+    uint64_t u = (uint64_t)__double_as_longlong(d);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double f64_unordered(uint64_t k) {
+    uint64_t u = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    return (uint64_t(1) << lane_id()) - 1;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_reduce_add(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_reduce_min(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { T w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_reduce_max(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { T w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    return v;
+}
+// inclusive wave scan
+template <typename T>
+__device__ __forceinline__ T wave_scan_incl(T v) {
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { T w = __shfl_up(v, o, 64); if (l >= o) v += w; }
+    return v;
+}
+#endif  // __HIPCC__
+
+}  // namespace pch

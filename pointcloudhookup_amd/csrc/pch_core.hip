@@ -1,0 +1,109 @@
+// Library plumbing: version, thread-local error text, per-kernel hipEvent profiling.
+#include "pch_common.h"
+
+#include <stdarg.h>
+#include <string>
+#include <vector>
+
+namespace pch {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct ProfRec {
+    const char* name;
+    hipEvent_t  e0, e1;
+};
+static thread_local bool                 g_prof_on = false;
+static thread_local std::vector<ProfRec> g_recs;
+static thread_local std::vector<hipEvent_t> g_pool;
+
+static hipEvent_t take_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+bool prof_enabled() { return g_prof_on; }
+
+void prof_begin_call() {
+    for (auto& r : g_recs) {
+        g_pool.push_back(r.e0);
+        g_pool.push_back(r.e1);
+    }
+    g_recs.clear();
+}
+
+void prof_pre(const char* name, hipStream_t s) {
+    ProfRec r;
+    r.name = name;
+    r.e0 = take_event();
+    r.e1 = take_event();
+    (void)hipEventRecord(r.e0, s);
+    g_recs.push_back(r);
+}
+
+void prof_post(hipStream_t s) { (void)hipEventRecord(g_recs.back().e1, s); }
+
+}  // namespace pch
+
+extern "C" {
+
+int pch_version(void) { return PCH_VERSION; }
+
+const char* pch_last_error(void) { return pch::g_err; }
+
+int pch_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void pch_set_profiling(int enable) {
+    pch::g_prof_on = enable != 0;
+    if (!enable) pch::prof_begin_call();
+}
+
+int pch_get_profile(int cap, char names[][48], float* ms, int* launches) {
+    using namespace pch;
+    // aggregate by kernel name, keeping first-seen order
+    std::vector<std::string> order;
+    std::vector<float> total;
+    std::vector<int> count;
+    for (auto& r : g_recs) {
+        if (hipEventSynchronize(r.e1) != hipSuccess) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) continue;
+        size_t k = 0;
+        for (; k < order.size(); ++k)
+            if (order[k] == r.name) break;
+        if (k == order.size()) {
+            order.push_back(r.name);
+            total.push_back(0.f);
+            count.push_back(0);
+        }
+        total[k] += t;
+        count[k] += 1;
+    }
+    int n = 0;
+    for (size_t k = 0; k < order.size() && n < cap; ++k, ++n) {
+        strncpy(names[n], order[k].c_str(), 47);
+        names[n][47] = 0;
+        ms[n] = total[k];
+        if (launches) launches[n] = count[k];
+    }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,614 @@
+// Stage C: exact DBSCAN for every file-order chunk at once (reference:
+// utils/tower_extraction.py:96-117 -> sklearn.cluster.DBSCAN(...).fit(chunk)).
+//
+// Method (grid DBSCAN, exact): points are binned into cubic cells of side
+//   s = eps/sqrt(3) * (1 - 2^-16)
+// so any two points of one cell are closer than eps under sklearn's own float64 predicate
+// (DESIGN.md "cell-side margin").  Consequences used below:
+//   * a cell holding >= min_samples points consists of core points only (no distance tests);
+//   * all core points of one cell belong to one cluster, so clusters are the connected
+//     components of a graph over CELLS (edge: some core pair of the two cells within eps);
+//   * every neighbour of a point lies in the 5x5x5 block of cells around its own cell.
+// Cell key = [chunk | cz | cy | cx] (x in the low bits), so for a fixed (dy,dz) the five
+// x-neighbour cells are one contiguous run of the sorted point array: 25 runs per cell.
+// Cluster numbering reproduces sklearn's sweep: id = rank of the component's smallest core
+// index; a border point takes the smallest id among its core neighbours.
+#include "pch_prims.h"
+
+namespace pch {
+
+constexpr int DB_THREADS = 256;
+constexpr int DB_WAVES   = DB_THREADS / 64;
+constexpr int DB_ROWS    = 25;
+constexpr int INT_BIG    = 0x7fffffff;
+
+struct DbGrid {
+    float   ox, oy, oz;          // grid origin (lower corner of the bounding box)
+    double  cell;                // cell side s
+    double  eps2;                // eps*eps (sklearn _dist_to_rdist)
+    int     bx, by, bz;          // key bits per axis
+    int     mx, my, mz;          // largest valid cell coordinate per axis
+    int64_t chunk_size;
+    int     min_samples;
+};
+
+// (dy,dz) rows ordered by distance so that early exits trigger as soon as possible
+__constant__ int8_t DB_ROW_DY[DB_ROWS] = {0, 1, -1, 0, 0, 1, 1, -1, -1, 2, -2, 0, 0,
+                                          2, 2, -2, -2, 1, 1, -1, -1, 2, 2, -2, -2};
+__constant__ int8_t DB_ROW_DZ[DB_ROWS] = {0, 0, 0, 1, -1, 1, -1, 1, -1, 0, 0, 2, -2,
+                                          1, -1, 1, -1, 2, -2, 2, -2, 2, -2, 2, -2};
+
+__device__ __forceinline__ uint64_t db_pack(const DbGrid& g, uint64_t chunk, uint64_t cz,
+                                            uint64_t cy, uint64_t cx) {
+    return ((((chunk << g.bz) | cz) << g.by | cy) << g.bx) | cx;
+}
+
+__device__ __forceinline__ bool db_within(const float4& q, const float4& p, double eps2) {
+    // euclidean_rdist: tmp = x1[j] - x2[j]; d += tmp * tmp   (float64, j = 0,1,2)
+    const double dx = (double)q.x - (double)p.x;
+    const double dy = (double)q.y - (double)p.y;
+    const double dz = (double)q.z - (double)p.z;
+    double d = dx * dx;
+    d += dy * dy;
+    d += dz * dz;
+    return d <= eps2;
+}
+
+// squared distance from a point to an axis-aligned box, same operation order as db_within;
+// never larger than the computed distance to any point inside the box (monotone rounding)
+__device__ __forceinline__ double db_box_d2(const float4& q, const float* __restrict__ box) {
+    const double gx = fmax(fmax((double)box[0] - (double)q.x, (double)q.x - (double)box[3]), 0.0);
+    const double gy = fmax(fmax((double)box[1] - (double)q.y, (double)q.y - (double)box[4]), 0.0);
+    const double gz = fmax(fmax((double)box[2] - (double)q.z, (double)q.z - (double)box[5]), 0.0);
+    double d = gx * gx;
+    d += gy * gy;
+    d += gz * gz;
+    return d;
+}
+__device__ __forceinline__ double db_boxbox_d2(const float* __restrict__ a, const float* __restrict__ b) {
+    const double gx = fmax(fmax((double)b[0] - (double)a[3], (double)a[0] - (double)b[3]), 0.0);
+    const double gy = fmax(fmax((double)b[1] - (double)a[4], (double)a[1] - (double)b[4]), 0.0);
+    const double gz = fmax(fmax((double)b[2] - (double)a[5], (double)a[2] - (double)b[5]), 0.0);
+    double d = gx * gx;
+    d += gy * gy;
+    d += gz * gz;
+    return d;
+}
+
+// ---- bounding box of the input (only when the caller did not provide one) ------------
+__global__ __launch_bounds__(DB_THREADS) void db_aabb_in_k(const float* __restrict__ xyz, int64_t n,
+                                                           uint32_t* __restrict__ mm) {
+    uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    for (int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * DB_THREADS) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const uint32_t k = f32_ordered(xyz[3 * i + a]);
+            lo[a] = k < lo[a] ? k : lo[a];
+            hi[a] = k > hi[a] ? k : hi[a];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = wave_reduce_min(lo[a]);
+        hi[a] = wave_reduce_max(hi[a]);
+        if (lane_id() == 0) { atomicMin(&mm[a], lo[a]); atomicMax(&mm[3 + a], hi[a]); }
+    }
+}
+
+// ---- cell keys -----------------------------------------------------------------------
+__global__ __launch_bounds__(DB_THREADS) void db_keys_k(const float* __restrict__ xyz, int64_t n,
+                                                        DbGrid g, uint64_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals,
+                                                        uint32_t* __restrict__ status) {
+    const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    const double fx = floor(((double)x - (double)g.ox) / g.cell);
+    const double fy = floor(((double)y - (double)g.oy) / g.cell);
+    const double fz = floor(((double)z - (double)g.oz) / g.cell);
+    const bool ok = fx >= 0.0 && fx <= (double)g.mx && fy >= 0.0 && fy <= (double)g.my &&
+                    fz >= 0.0 && fz <= (double)g.mz;       // false for NaN / out of box
+    if (!ok) atomicOr(status, 1u);
+    const uint64_t cx = ok ? (uint64_t)fx : 0, cy = ok ? (uint64_t)fy : 0, cz = ok ? (uint64_t)fz : 0;
+    keys[i] = db_pack(g, (uint64_t)(i / g.chunk_size), cz, cy, cx);
+    vals[i] = (uint32_t)i;
+}
+
+// sorted order: gather coordinates (+ original row in .w) and flag cell heads
+__global__ __launch_bounds__(DB_THREADS) void db_gather_k(const float* __restrict__ xyz,
+                                                          const uint64_t* __restrict__ keys,
+                                                          const uint32_t* __restrict__ vals, int64_t n,
+                                                          float4* __restrict__ pts,
+                                                          uint32_t* __restrict__ head) {
+    const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t o = vals[i];
+    float4 p;
+    p.x = xyz[3 * (int64_t)o + 0];
+    p.y = xyz[3 * (int64_t)o + 1];
+    p.z = xyz[3 * (int64_t)o + 2];
+    p.w = __uint_as_float(o);
+    pts[i] = p;
+    head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(DB_THREADS) void db_cells_k(const uint64_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ excl, int64_t n,
+                                                         uint32_t* __restrict__ cid,
+                                                         uint32_t* __restrict__ cell_start,
+                                                         uint64_t* __restrict__ cell_key) {
+    const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const bool head = (i == 0 || keys[i] != keys[i - 1]);
+    const uint32_t c = excl[i] + (head ? 1u : 0u) - 1u;
+    cid[i] = c;
+    if (head) { cell_start[c] = (uint32_t)i; cell_key[c] = keys[i]; }
+    if (i == n - 1) cell_start[c + 1] = (uint32_t)n;
+}
+
+// ---- neighbour rows of one cell: lanes 0..24 each binary-search one (dy,dz) row ---------
+struct RowSet {
+    int ca[DB_ROWS], cb[DB_ROWS];      // cell index range of every row
+};
+
+__device__ __forceinline__ int db_lower(const uint64_t* __restrict__ a, int m, uint64_t k) {
+    int lo = 0, hi = m;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < k) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__device__ __forceinline__ int db_upper(const uint64_t* __restrict__ a, int m, uint64_t k) {
+    int lo = 0, hi = m;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] <= k) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+__device__ __forceinline__ void db_rows(const DbGrid& g, const uint64_t* __restrict__ cell_key, int m,
+                                        uint64_t key, RowSet* __restrict__ rs) {
+    const int l = lane_id();
+    if (l < DB_ROWS) {
+        const uint64_t cx = key & ((1ull << g.bx) - 1);
+        const uint64_t cy = (key >> g.bx) & ((1ull << g.by) - 1);
+        const uint64_t cz = (key >> (g.bx + g.by)) & ((1ull << g.bz) - 1);
+        const int sh = g.bx + g.by + g.bz;
+        const uint64_t chunk = sh < 64 ? (key >> sh) : 0;
+        const int ny = (int)cy + DB_ROW_DY[l], nz = (int)cz + DB_ROW_DZ[l];
+        int a = 0, b = 0;
+        if (ny >= 0 && ny <= g.my && nz >= 0 && nz <= g.mz) {
+            const int xlo = (int)cx - 2 < 0 ? 0 : (int)cx - 2;
+            const int xhi = (int)cx + 2 > g.mx ? g.mx : (int)cx + 2;
+            a = db_lower(cell_key, m, db_pack(g, chunk, (uint64_t)nz, (uint64_t)ny, (uint64_t)xlo));
+            b = db_upper(cell_key, m, db_pack(g, chunk, (uint64_t)nz, (uint64_t)ny, (uint64_t)xhi));
+        }
+        rs->ca[l] = a;
+        rs->cb[l] = b;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- core points ---------------------------------------------------------------------
+// one wave per cell.  Dense cell: all core.  Sparse cell: per query point, lanes sweep the
+// candidate runs and count with ballot/popcount, leaving as soon as min_samples is reached.
+__global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* __restrict__ pts,
+                                                        const uint32_t* __restrict__ cell_start,
+                                                        const uint64_t* __restrict__ cell_key, int m,
+                                                        uint8_t* __restrict__ core_s,
+                                                        uint32_t* __restrict__ cell_ncore) {
+    __shared__ RowSet rows[DB_WAVES];
+    const int c = blockIdx.x * DB_WAVES + wave_id();
+    if (c >= m) return;
+    const int l = lane_id();
+    const uint32_t s = cell_start[c], e = cell_start[c + 1];
+    const int cnt = (int)(e - s);
+    if (cnt >= g.min_samples) {
+        for (uint32_t i = s + l; i < e; i += 64) core_s[i] = 1;
+        if (l == 0) cell_ncore[c] = (uint32_t)cnt;
+        return;
+    }
+    RowSet* rs = &rows[wave_id()];
+    db_rows(g, cell_key, m, cell_key[c], rs);
+    // candidate total: if even all candidates together are too few, nobody is core
+    long long tot = 0;
+    if (l < DB_ROWS) tot = (long long)cell_start[rs->cb[l]] - (long long)cell_start[rs->ca[l]];
+    tot = wave_reduce_add(tot);
+    if (tot < (long long)g.min_samples) {
+        for (uint32_t i = s + l; i < e; i += 64) core_s[i] = 0;
+        if (l == 0) cell_ncore[c] = 0;
+        return;
+    }
+    uint32_t ncore = 0;
+    for (uint32_t q = s; q < e; ++q) {
+        const float4 qp = pts[q];
+        int count = 0;
+        for (int r = 0; r < DB_ROWS && count < g.min_samples; ++r) {
+            const uint32_t pa = cell_start[rs->ca[r]], pb = cell_start[rs->cb[r]];
+            for (uint32_t j0 = pa; j0 < pb && count < g.min_samples; j0 += 64) {
+                const uint32_t j = j0 + l;
+                bool hit = false;
+                if (j < pb) hit = db_within(qp, pts[j], g.eps2);
+                count += (int)__popcll(__ballot(hit));
+            }
+        }
+        const bool is_core = count >= g.min_samples;
+        if (l == 0) core_s[q] = is_core ? 1 : 0;
+        ncore += is_core;
+    }
+    if (l == 0) cell_ncore[c] = ncore;
+}
+
+// ---- per-cell box of the core points, union-find init ----------------------------------
+__global__ __launch_bounds__(DB_THREADS) void db_cellbox_k(const float4* __restrict__ pts,
+                                                           const uint32_t* __restrict__ cell_start,
+                                                           const uint8_t* __restrict__ core_s, int m,
+                                                           float* __restrict__ cell_box,
+                                                           int* __restrict__ parent,
+                                                           int* __restrict__ comp_min) {
+    const int c = blockIdx.x * DB_WAVES + wave_id();
+    if (c >= m) return;
+    const int l = lane_id();
+    const uint32_t s = cell_start[c], e = cell_start[c + 1];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = s + l; i < e; i += 64) {
+        if (core_s[i]) {
+            const float4 p = pts[i];
+            lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+            lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+            lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = wave_reduce_min(lo[a]); hi[a] = wave_reduce_max(hi[a]); }
+    if (l == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { cell_box[6 * (int64_t)c + a] = lo[a]; cell_box[6 * (int64_t)c + 3 + a] = hi[a]; }
+        parent[c] = c;
+        comp_min[c] = INT_BIG;
+    }
+}
+
+// ---- union-find over cells (hook larger root under smaller; lock free) ------------------
+__device__ __forceinline__ int uf_load(int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int uf_find(int* __restrict__ parent, int x) {
+    int p = uf_load(&parent[x]);
+    while (p != x) {
+        const int gp = uf_load(&parent[p]);
+        if (gp != p) atomicMin(&parent[x], gp);     // path halving; only ever moves x to an ancestor
+        x = p;
+        p = gp;
+    }
+    return x;
+}
+__device__ __forceinline__ void uf_union(int* __restrict__ parent, int a, int b) {
+    for (;;) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }   // a > b: hook a under b
+        const int old = atomicCAS(&parent[a], a, b);
+        if (old == a) return;
+    }
+}
+
+// one wave per core cell A: for every neighbour core cell B > A not yet in A's component,
+// look for one core pair within eps (lanes over B's points, scalar loop over A's points,
+// leave at the first hit), then unite.
+__global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4* __restrict__ pts,
+                                                         const uint32_t* __restrict__ cell_start,
+                                                         const uint64_t* __restrict__ cell_key, int m,
+                                                         const uint8_t* __restrict__ core_s,
+                                                         const uint32_t* __restrict__ cell_ncore,
+                                                         const float* __restrict__ cell_box,
+                                                         int* __restrict__ parent) {
+    __shared__ RowSet rows[DB_WAVES];
+    const int A = blockIdx.x * DB_WAVES + wave_id();
+    if (A >= m) return;
+    if (cell_ncore[A] == 0) return;
+    const int l = lane_id();
+    RowSet* rs = &rows[wave_id()];
+    db_rows(g, cell_key, m, cell_key[A], rs);
+    const uint32_t as = cell_start[A], ae = cell_start[A + 1];
+    const bool a_dense = cell_ncore[A] == (ae - as);
+    const float* boxA = cell_box + 6 * (int64_t)A;
+    for (int r = 0; r < DB_ROWS; ++r) {
+        const int cb = rs->cb[r];
+        for (int B = rs->ca[r]; B < cb; ++B) {
+            if (B <= A) continue;                          // every unordered pair once
+            const uint32_t nb = cell_ncore[B];
+            if (nb == 0) continue;
+            const float* boxB = cell_box + 6 * (int64_t)B;
+            if (db_boxbox_d2(boxA, boxB) > g.eps2) continue;
+            int same = 0;
+            if (l == 0) same = uf_find(parent, A) == uf_find(parent, B);
+            if (__shfl(same, 0, 64)) continue;
+            const uint32_t bs = cell_start[B], be = cell_start[B + 1];
+            const bool b_dense = nb == (be - bs);
+            bool connected = false;
+            for (uint32_t ia = as; ia < ae && !connected; ++ia) {
+                if (!a_dense && !core_s[ia]) continue;
+                const float4 pa = pts[ia];
+                if (db_box_d2(pa, boxB) > g.eps2) continue;
+                for (uint32_t j0 = bs; j0 < be; j0 += 64) {
+                    const uint32_t j = j0 + l;
+                    bool hit = false;
+                    if (j < be && (b_dense || core_s[j])) hit = db_within(pa, pts[j], g.eps2);
+                    if (__ballot(hit)) { connected = true; break; }
+                }
+            }
+            if (connected && l == 0) uf_union(parent, A, B);
+        }
+    }
+}
+
+// root of every core cell + smallest original row among the component's core points
+__global__ __launch_bounds__(DB_THREADS) void db_compmin_k(const float4* __restrict__ pts,
+                                                           const uint32_t* __restrict__ cell_start,
+                                                           const uint8_t* __restrict__ core_s,
+                                                           const uint32_t* __restrict__ cell_ncore, int m,
+                                                           int* __restrict__ parent,
+                                                           int* __restrict__ root,
+                                                           int* __restrict__ comp_min) {
+    const int c = blockIdx.x * DB_WAVES + wave_id();
+    if (c >= m) return;
+    const int l = lane_id();
+    if (cell_ncore[c] == 0) { if (l == 0) root[c] = -1; return; }
+    const uint32_t s = cell_start[c], e = cell_start[c + 1];
+    int mn = INT_BIG;
+    for (uint32_t i = s + l; i < e; i += 64)
+        if (core_s[i]) { const int o = (int)__float_as_uint(pts[i].w); mn = o < mn ? o : mn; }
+    mn = wave_reduce_min(mn);
+    if (l == 0) {
+        const int r = uf_find(parent, c);
+        root[c] = r;
+        atomicMin(&comp_min[r], mn);
+    }
+}
+
+__global__ __launch_bounds__(DB_THREADS) void db_mark_k(const int* __restrict__ root,
+                                                        const int* __restrict__ comp_min, int m,
+                                                        uint32_t* __restrict__ flag) {
+    const int c = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (c >= m) return;
+    if (root[c] == c) flag[comp_min[c]] = 1u;
+}
+
+// labels of core points (original order), label of every cell, optional core mask
+__global__ __launch_bounds__(DB_THREADS) void db_label_k(const float4* __restrict__ pts,
+                                                         const uint32_t* __restrict__ cid,
+                                                         const uint8_t* __restrict__ core_s,
+                                                         const int* __restrict__ root,
+                                                         const int* __restrict__ comp_min,
+                                                         const uint32_t* __restrict__ rank, int64_t n,
+                                                         const uint32_t* __restrict__ cell_start,
+                                                         int* __restrict__ cell_label,
+                                                         int32_t* __restrict__ labels,
+                                                         uint8_t* __restrict__ core_out) {
+    const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = cid[i];
+    const int r = root[c];
+    const int lab = r >= 0 ? (int)rank[comp_min[r]] : INT_BIG;
+    const uint32_t o = __float_as_uint(pts[i].w);
+    const bool is_core = core_s[i] != 0;
+    labels[o] = is_core ? lab : -1;
+    if (core_out) core_out[o] = is_core ? 1 : 0;
+    if (cell_start[c] == (uint32_t)i) cell_label[c] = lab;
+}
+
+// border points: smallest cluster id among the core points within eps
+__global__ __launch_bounds__(DB_THREADS) void db_border_k(DbGrid g, const float4* __restrict__ pts,
+                                                          const uint32_t* __restrict__ cell_start,
+                                                          const uint64_t* __restrict__ cell_key, int m,
+                                                          const uint8_t* __restrict__ core_s,
+                                                          const uint32_t* __restrict__ cell_ncore,
+                                                          const float* __restrict__ cell_box,
+                                                          const int* __restrict__ cell_label,
+                                                          int32_t* __restrict__ labels) {
+    __shared__ RowSet rows[DB_WAVES];
+    const int A = blockIdx.x * DB_WAVES + wave_id();
+    if (A >= m) return;
+    const uint32_t as = cell_start[A], ae = cell_start[A + 1];
+    if (cell_ncore[A] == (ae - as)) return;                // no border candidates here
+    const int l = lane_id();
+    RowSet* rs = &rows[wave_id()];
+    db_rows(g, cell_key, m, cell_key[A], rs);
+    // quick reject: no core cell anywhere around
+    int any = 0;
+    if (l < DB_ROWS)
+        for (int B = rs->ca[l]; B < rs->cb[l]; ++B) any |= (cell_ncore[B] != 0);
+    if (!__ballot(any != 0)) return;
+    for (uint32_t q = as; q < ae; ++q) {
+        if (core_s[q]) continue;
+        const float4 qp = pts[q];
+        int best = INT_BIG;
+        for (int r = 0; r < DB_ROWS; ++r) {
+            const int cb = rs->cb[r];
+            for (int B = rs->ca[r]; B < cb; ++B) {
+                const uint32_t nb = cell_ncore[B];
+                if (nb == 0) continue;
+                const int lab = cell_label[B];
+                if (lab >= best) continue;
+                if (db_box_d2(qp, cell_box + 6 * (int64_t)B) > g.eps2) continue;
+                const uint32_t bs = cell_start[B], be = cell_start[B + 1];
+                const bool b_dense = nb == (be - bs);
+                for (uint32_t j0 = bs; j0 < be; j0 += 64) {
+                    const uint32_t j = j0 + l;
+                    bool hit = false;
+                    if (j < be && (b_dense || core_s[j])) hit = db_within(qp, pts[j], g.eps2);
+                    if (__ballot(hit)) { best = lab; break; }
+                }
+            }
+        }
+        if (l == 0 && best != INT_BIG) labels[__float_as_uint(qp.w)] = best;
+    }
+}
+
+__global__ void db_finish_k(const uint32_t* __restrict__ total, int32_t* __restrict__ out_nclusters) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out_nclusters = (int32_t)*total;
+}
+
+struct DbWs {
+    uint32_t* meta;         // [0..5] aabb ordered keys, [6] status, [7] m, [8] nclusters
+    uint64_t *k0, *k1, *cell_key;
+    uint32_t *v0, *v1, *head, *cid, *cell_start, *cell_ncore, *flag, *radix_ws, *scan_ws;
+    float4*   pts;
+    uint8_t*  core_s;
+    float*    cell_box;
+    int      *parent, *root, *comp_min, *cell_label;
+};
+
+static void db_plan(Arena& a, int64_t n, DbWs& w) {
+    const int64_t nn = n > 0 ? n : 1;
+    w.meta = a.take<uint32_t>(16);
+    w.k0 = a.take<uint64_t>(nn);
+    w.k1 = a.take<uint64_t>(nn);
+    w.v0 = a.take<uint32_t>(nn);
+    w.v1 = a.take<uint32_t>(nn);
+    w.head = a.take<uint32_t>(nn + 8);
+    w.cid = a.take<uint32_t>(nn);
+    w.pts = a.take<float4>(nn);
+    w.core_s = a.take<uint8_t>(nn);
+    w.cell_key = a.take<uint64_t>(nn);
+    w.cell_start = a.take<uint32_t>(nn + 8);
+    w.cell_ncore = a.take<uint32_t>(nn);
+    w.cell_box = a.take<float>(6 * nn);
+    w.parent = a.take<int>(nn);
+    w.root = a.take<int>(nn);
+    w.comp_min = a.take<int>(nn);
+    w.cell_label = a.take<int>(nn);
+    w.flag = a.take<uint32_t>(nn + 8);
+    w.radix_ws = a.take<uint32_t>(radix_ws_u32(nn));
+    w.scan_ws = a.take<uint32_t>(scan_ws_u32(nn));
+}
+
+// host mirror of f32_unordered
+static float host_unordered(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+}  // namespace pch
+
+using namespace pch;
+
+extern "C" size_t pch_dbscan_ws_bytes(int64_t n) {
+    if (n < 0) return 0;
+    Arena a;
+    DbWs w;
+    db_plan(a, n, w);
+    return a.off;
+}
+
+extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t min_samples,
+                              int64_t chunk_size, const float* aabb_host, int32_t* labels,
+                              uint8_t* core, int32_t* out_nclusters, void* ws, size_t ws_bytes,
+                              void* stream) {
+    prof_begin_call();
+    hipStream_t s = (hipStream_t)stream;
+    PCH_REQUIRE(n >= 0 && n < (int64_t(1) << 31), "n out of range [0, 2^31)");
+    PCH_REQUIRE(eps > 0.0, "eps must be > 0 (sklearn: InvalidParameterError)");
+    PCH_REQUIRE(min_samples >= 1, "min_samples must be >= 1 (sklearn: InvalidParameterError)");
+    PCH_REQUIRE(out_nclusters != nullptr, "out_nclusters is null");
+    if (n == 0) {
+        PCH_HIP_TRY(hipMemsetAsync(out_nclusters, 0, sizeof(int32_t), s));
+        return PCH_OK;
+    }
+    PCH_REQUIRE(xyz && labels && ws, "null buffer");
+    Arena a(ws, ws_bytes);
+    DbWs w;
+    db_plan(a, n, w);
+    if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
+    if (chunk_size <= 0 || chunk_size > n) chunk_size = n;
+    const int64_t nchunks = ceil_div(n, chunk_size);
+
+    float box[6];
+    if (aabb_host) {
+        memcpy(box, aabb_host, sizeof(box));
+    } else {
+        PCH_HIP_TRY(hipMemsetAsync(w.meta, 0xFF, 3 * sizeof(uint32_t), s));
+        PCH_HIP_TRY(hipMemsetAsync(w.meta + 3, 0, 3 * sizeof(uint32_t), s));
+        int64_t gb = ceil_div(n, DB_THREADS * 8);
+        if (gb > 2048) gb = 2048;
+        PCH_LAUNCH("db_aabb_in", db_aabb_in_k, dim3((unsigned)gb), dim3(DB_THREADS), 0, s, xyz, n, w.meta);
+        uint32_t mm[6];
+        PCH_HIP_TRY(hipMemcpyAsync(mm, w.meta, sizeof(mm), hipMemcpyDeviceToHost, s));
+        PCH_HIP_TRY(hipStreamSynchronize(s));
+        for (int k = 0; k < 6; ++k) box[k] = host_unordered(mm[k]);
+    }
+    for (int k = 0; k < 6; ++k) {
+        if (!(box[k] == box[k]) || box[k] > 3.0e38f || box[k] < -3.0e38f) {
+            set_error("non-finite coordinates (sklearn: ValueError: Input contains NaN/inf)");
+            return PCH_ERR_ARG;
+        }
+    }
+    DbGrid g;
+    g.ox = box[0]; g.oy = box[1]; g.oz = box[2];
+    g.cell = eps / 1.7320508075688772 * (1.0 - 1.0 / 65536.0);
+    g.eps2 = eps * eps;
+    g.chunk_size = chunk_size;
+    g.min_samples = min_samples;
+    double ext[3];
+    int mc[3];
+    for (int k = 0; k < 3; ++k) {
+        ext[k] = ((double)box[3 + k] - (double)box[k]) / g.cell;
+        if (!(ext[k] < 2.0e9)) { set_error("cell grid too large (extent/eps too big)"); return PCH_ERR_RANGE; }
+        mc[k] = (int)ext[k] + 1;                 // +1: slack for the rounding of the division
+    }
+    g.mx = mc[0]; g.my = mc[1]; g.mz = mc[2];
+    g.bx = bits_for((uint64_t)g.mx + 1);
+    g.by = bits_for((uint64_t)g.my + 1);
+    g.bz = bits_for((uint64_t)g.mz + 1);
+    const int nbits = g.bx + g.by + g.bz + bits_for((uint64_t)nchunks);
+    if (nbits > 64) {
+        set_error("cell key needs %d bits (> 64): extent/eps too large for this chunking", nbits);
+        return PCH_ERR_RANGE;
+    }
+
+    const unsigned gn = (unsigned)ceil_div(n, DB_THREADS);
+    PCH_HIP_TRY(hipMemsetAsync(w.meta + 6, 0, 4 * sizeof(uint32_t), s));
+    PCH_LAUNCH("db_keys", db_keys_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, n, g, w.k0, w.v0, w.meta + 6);
+    PCH_TRY(radix_sort_pairs(w.k0, w.v0, w.k1, w.v1, n, nbits, w.radix_ws, s));
+    const bool in1 = radix_sort_result_buffer(nbits) == 1;
+    const uint64_t* ks = in1 ? w.k1 : w.k0;
+    const uint32_t* vs = in1 ? w.v1 : w.v0;
+    PCH_LAUNCH("db_gather", db_gather_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, ks, vs, n, w.pts, w.head);
+    PCH_TRY(scan_exclusive_u32(w.head, w.head, n, w.scan_ws, w.meta + 7, s));
+    uint32_t st_m[2];
+    PCH_HIP_TRY(hipMemcpyAsync(st_m, w.meta + 6, sizeof(st_m), hipMemcpyDeviceToHost, s));
+    PCH_HIP_TRY(hipStreamSynchronize(s));
+    if (st_m[0] != 0) {
+        set_error("coordinates outside the supplied bounding box or non-finite "
+                  "(sklearn: ValueError: Input contains NaN/inf)");
+        return PCH_ERR_ARG;
+    }
+    const int m = (int)st_m[1];
+    PCH_LAUNCH("db_cells", db_cells_k, dim3(gn), dim3(DB_THREADS), 0, s, ks, (const uint32_t*)w.head, n,
+               w.cid, w.cell_start, w.cell_key);
+    const unsigned gc = (unsigned)ceil_div(m, DB_WAVES);
+    PCH_LAUNCH("db_core", db_core_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
+               (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, w.core_s, w.cell_ncore);
+    PCH_LAUNCH("db_cellbox", db_cellbox_k, dim3(gc), dim3(DB_THREADS), 0, s, (const float4*)w.pts,
+               (const uint32_t*)w.cell_start, (const uint8_t*)w.core_s, m, w.cell_box, w.parent, w.comp_min);
+    PCH_LAUNCH("db_union", db_union_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
+               (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, (const uint8_t*)w.core_s,
+               (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, w.parent);
+    PCH_LAUNCH("db_compmin", db_compmin_k, dim3(gc), dim3(DB_THREADS), 0, s, (const float4*)w.pts,
+               (const uint32_t*)w.cell_start, (const uint8_t*)w.core_s, (const uint32_t*)w.cell_ncore, m,
+               w.parent, w.root, w.comp_min);
+    PCH_HIP_TRY(hipMemsetAsync(w.flag, 0, sizeof(uint32_t) * (size_t)n, s));
+    PCH_LAUNCH("db_mark", db_mark_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
+               (const int*)w.root, (const int*)w.comp_min, m, w.flag);
+    PCH_TRY(scan_exclusive_u32(w.flag, w.flag, n, w.scan_ws, w.meta + 8, s));
+    PCH_LAUNCH("db_label", db_label_k, dim3(gn), dim3(DB_THREADS), 0, s, (const float4*)w.pts,
+               (const uint32_t*)w.cid, (const uint8_t*)w.core_s, (const int*)w.root,
+               (const int*)w.comp_min, (const uint32_t*)w.flag, n, (const uint32_t*)w.cell_start,
+               w.cell_label, labels, core);
+    PCH_LAUNCH("db_border", db_border_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
+               (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, (const uint8_t*)w.core_s,
+               (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, (const int*)w.cell_label, labels);
+    PCH_LAUNCH("db_finish", db_finish_k, dim3(1), dim3(64), 0, s, (const uint32_t*)(w.meta + 8), out_nclusters);
+    return PCH_OK;
+}

@@ -1,0 +1,478 @@
+// Stage B: float32 centroid (numpy sequential-sum semantics), centring, numpy 'linear'
+// percentile by radix select, and the order-preserving height-filter compaction.
+// Reference: utils/tower_extraction.py:62-64 (centroid, centring), :82-89 (percentile filter).
+#include "pch_prims.h"
+
+namespace pch {
+
+// =====================================================================================
+// B1: np.mean(raw, axis=0) on a C-order (n,3) float32 array == sequential float32 running
+// sum per column, then one float32 division by float32(n).
+// v0 implementation: one workgroup streams tiles through LDS, lanes 0..2 carry the three
+// (inherently ordered) accumulation chains.
+// =====================================================================================
+constexpr int MS_TILE = 4096;   // points per LDS tile (48 KiB)
+
+__global__ __launch_bounds__(256) void mean_seq_k(const float* __restrict__ xyz, int64_t n,
+                                                  float* __restrict__ out) {
+    __shared__ float tile[MS_TILE * 3];
+    float s = 0.0f;
+    for (int64_t base = 0; base < n; base += MS_TILE) {
+        const int cnt = (int)((n - base) < MS_TILE ? (n - base) : MS_TILE);
+        const float* src = xyz + 3 * base;
+        for (int e = threadIdx.x; e < 3 * cnt; e += 256) tile[e] = src[e];
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const float* col = tile + threadIdx.x;
+            int i = 0;
+            for (; i + 8 <= cnt; i += 8) {
+                const float a0 = col[3 * (i + 0)], a1 = col[3 * (i + 1)], a2 = col[3 * (i + 2)],
+                            a3 = col[3 * (i + 3)], a4 = col[3 * (i + 4)], a5 = col[3 * (i + 5)],
+                            a6 = col[3 * (i + 6)], a7 = col[3 * (i + 7)];
+                s = s + a0; s = s + a1; s = s + a2; s = s + a3;
+                s = s + a4; s = s + a5; s = s + a6; s = s + a7;
+            }
+            for (; i < cnt; ++i) s = s + col[3 * i];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) out[threadIdx.x] = s / (float)n;   // n == 0 -> 0/0 = NaN like numpy
+}
+
+// =====================================================================================
+// B2: k-th order statistics of v[i] = base[i*stride] - sub by 12/12/8-bit radix select on the
+// order-preserving uint32 image of the float.  NaN sorts last (as numpy's partition).
+// =====================================================================================
+constexpr int SEL_BINS = 4096;
+
+struct SelState {
+    unsigned long long rank;       // remaining rank inside the current prefix
+    unsigned long long less;       // elements strictly below the current prefix
+    uint32_t prefix;               // resolved high bits
+    uint32_t need_next;            // 1: k1 is not inside the final bin of k0
+    uint32_t v0key, v1key;
+    unsigned long long nan_count;
+    uint32_t next_min;             // min key > v0key (pass 4)
+    uint32_t pad;
+};
+
+__device__ __forceinline__ uint32_t sel_key(float v) {
+    return (v != v) ? 0xFFFFFFFFu : f32_ordered(v);
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void sel_hist_k(const float* __restrict__ base, int64_t n,
+                                                  int64_t stride, const float* __restrict__ sub,
+                                                  SelState* __restrict__ st,
+                                                  uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[SEL_BINS];
+    for (int j = threadIdx.x; j < SEL_BINS; j += 256) h[j] = 0;
+    __syncthreads();
+    const float c = sub ? *sub : 0.0f;
+    const uint32_t prefix = st->prefix;
+    unsigned long long nans = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = base[i * stride] - c;
+        const uint32_t k = sel_key(v);
+        if (PASS == 0) {
+            atomicAdd(&h[k >> 20], 1u);
+            nans += (v != v);
+        } else if (PASS == 1) {
+            if ((k >> 20) == prefix) atomicAdd(&h[(k >> 8) & 0xFFFu], 1u);
+        } else {
+            if ((k >> 8) == prefix) atomicAdd(&h[k & 0xFFu], 1u);
+        }
+    }
+    __syncthreads();
+    const int nb = (PASS == 2) ? 256 : SEL_BINS;
+    for (int j = threadIdx.x; j < nb; j += 256)
+        if (h[j]) atomicAdd(&hist[j], h[j]);
+    if (PASS == 0) {
+        nans = wave_reduce_add(nans);
+        if (lane_id() == 0 && nans) atomicAdd(&st->nan_count, nans);
+    }
+}
+
+// single workgroup: locate the bin holding the wanted rank, extend the prefix, clear hist
+template <int PASS>
+__global__ __launch_bounds__(256) void sel_pick_k(SelState* __restrict__ st, uint32_t* __restrict__ hist) {
+    __shared__ unsigned long long wsum[4];
+    __shared__ int found_bin;
+    __shared__ unsigned long long found_below;
+    const int nb = (PASS == 2) ? 256 : SEL_BINS;
+    const int per = nb / 256;                       // bins per thread (16 or 1)
+    const unsigned long long rank = st->rank;
+    unsigned long long loc[16];
+    unsigned long long tsum = 0;
+    for (int j = 0; j < per; ++j) { loc[j] = hist[threadIdx.x * per + j]; tsum += loc[j]; }
+    const unsigned long long incl = wave_scan_incl(tsum);
+    if (lane_id() == 63) wsum[wave_id()] = incl;
+    if (threadIdx.x == 0) found_bin = -1;
+    __syncthreads();
+    unsigned long long before = incl - tsum;
+    for (int w = 0; w < wave_id(); ++w) before += wsum[w];
+    // the thread whose bin range [before, before+tsum) contains rank owns the answer
+    if (rank >= before && rank < before + tsum) {
+        unsigned long long b = before;
+        for (int j = 0; j < per; ++j) {
+            if (rank < b + loc[j]) { found_bin = threadIdx.x * per + j; found_below = b; break; }
+            b += loc[j];
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nb; j += 256) {
+        if (PASS == 2 && j == found_bin) {
+            // does rank+1 (the 'next' order statistic) still fall into this final bin?
+            const unsigned long long cnt = hist[j];
+            st->need_next = (rank + 1 < found_below + cnt) ? 0u : 1u;
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nb; j += 256) hist[j] = 0;
+    if (threadIdx.x == 0) {
+        const int bin = found_bin < 0 ? 0 : found_bin;   // n == 0 never reaches here
+        st->less += found_below;
+        st->rank = rank - found_below;
+        if (PASS == 0) st->prefix = (uint32_t)bin;
+        else if (PASS == 1) st->prefix = (st->prefix << 12) | (uint32_t)bin;
+        else { st->v0key = (st->prefix << 8) | (uint32_t)bin; st->next_min = 0xFFFFFFFFu; }
+    }
+}
+
+// pass 4 (only when needed): smallest key strictly above v0key
+__global__ __launch_bounds__(256) void sel_next_k(const float* __restrict__ base, int64_t n,
+                                                  int64_t stride, const float* __restrict__ sub,
+                                                  SelState* __restrict__ st) {
+    if (st->need_next == 0) return;
+    const float c = sub ? *sub : 0.0f;
+    const uint32_t v0 = st->v0key;
+    uint32_t best = 0xFFFFFFFFu;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t k = sel_key(base[i * stride] - c);
+        if (k > v0 && k < best) best = k;
+    }
+    best = wave_reduce_min(best);
+    if (lane_id() == 0 && best != 0xFFFFFFFFu) atomicMin(&st->next_min, best);
+}
+
+__device__ __forceinline__ float sel_key_to_float(uint32_t k) {
+    return (k == 0xFFFFFFFFu) ? __uint_as_float(0x7FC00000u) : f32_unordered(k);
+}
+
+// numpy _lerp in float32: a + (b-a)*t, and b - (b-a)*(1-t) where t >= 0.5
+// (numpy/lib/_function_base_impl.py:4639-4660); NaN anywhere -> NaN.
+// scal: [0] = percentile, [1] = percentile + add1, [2] = percentile + add2
+__global__ void sel_lerp_k(const SelState* __restrict__ st, int same_index, float gamma,
+                           float add1, float add2, float* __restrict__ scal) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float a = sel_key_to_float(st->v0key);
+    float b = a;
+    if (!same_index && st->need_next) b = sel_key_to_float(st->next_min);
+    const float diff = b - a;
+    float r = a + diff * gamma;
+    if (gamma >= 0.5f) r = b - diff * (1.0f - gamma);
+    if (st->nan_count) r = __uint_as_float(0x7FC00000u);
+    scal[0] = r;
+    scal[1] = r + add1;
+    scal[2] = r + add2;
+}
+
+__global__ void sel_init_k(SelState* st, unsigned long long rank) { st->rank = rank; }
+
+struct SelWs {
+    SelState* st;
+    uint32_t* hist;
+    float*    scal;     // 4 floats
+};
+static void sel_plan(Arena& a, SelWs& w) {
+    w.st = a.take<SelState>(1);
+    w.hist = a.take<uint32_t>(SEL_BINS);
+    w.scal = a.take<float>(4);
+}
+
+// host side of np.percentile's index arithmetic (float32 under NEP 50)
+struct PctIndex { int64_t k0; int same; float gamma; };
+static PctIndex pct_index(int64_t n, double q_percent) {
+    PctIndex r;
+    const float q = (float)q_percent / 100.0f;          // np.true_divide(q, float32(100))
+    const float vi = (float)(n - 1) * q;                // (n - 1) * quantiles -> float32
+    float prev = floorf(vi);
+    r.gamma = vi - prev;
+    r.same = 0;
+    if (vi >= (float)(n - 1)) { prev = (float)(n - 1); r.same = 1; }   // indexes -> -1 (last)
+    if (vi < 0.0f) { prev = 0.0f; r.same = 1; }
+    int64_t k0 = (int64_t)prev;
+    if (k0 > n - 1) k0 = n - 1;                          // float32(n-1) may round up
+    if (k0 < 0) k0 = 0;
+    if (k0 == n - 1) r.same = 1;
+    r.k0 = k0;
+    return r;
+}
+
+static int select_percentile(const float* base, int64_t n, int64_t stride, const float* sub,
+                             double q_percent, float add1, float add2, SelWs& w, hipStream_t s) {
+    const PctIndex pi = pct_index(n, q_percent);
+    SelState init;
+    memset(&init, 0, sizeof(init));
+    init.rank = (unsigned long long)pi.k0;
+    PCH_HIP_TRY(hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * SEL_BINS, s));
+    PCH_HIP_TRY(hipMemsetAsync(w.st, 0, sizeof(SelState), s));
+    PCH_LAUNCH("sel_init", sel_init_k, dim3(1), dim3(1), 0, s, w.st, init.rank);
+    int64_t gb = ceil_div(n, 256 * 16);
+    if (gb > 4096) gb = 4096;
+    if (gb < 1) gb = 1;
+    const dim3 grid((unsigned)gb), blk(256);
+    PCH_LAUNCH("sel_hist0", sel_hist_k<0>, grid, blk, 0, s, base, n, stride, sub, w.st, w.hist);
+    PCH_LAUNCH("sel_pick0", sel_pick_k<0>, dim3(1), blk, 0, s, w.st, w.hist);
+    PCH_LAUNCH("sel_hist1", sel_hist_k<1>, grid, blk, 0, s, base, n, stride, sub, w.st, w.hist);
+    PCH_LAUNCH("sel_pick1", sel_pick_k<1>, dim3(1), blk, 0, s, w.st, w.hist);
+    PCH_LAUNCH("sel_hist2", sel_hist_k<2>, grid, blk, 0, s, base, n, stride, sub, w.st, w.hist);
+    PCH_LAUNCH("sel_pick2", sel_pick_k<2>, dim3(1), blk, 0, s, w.st, w.hist);
+    if (!pi.same)
+        PCH_LAUNCH("sel_next", sel_next_k, grid, blk, 0, s, base, n, stride, sub, w.st);
+    PCH_LAUNCH("sel_lerp", sel_lerp_k, dim3(1), dim3(64), 0, s, (const SelState*)w.st, pi.same, pi.gamma,
+               add1, add2, w.scal);
+    return PCH_OK;
+}
+
+// =====================================================================================
+// B2/B3: keep = (z - cz) > thr, order preserving.  Two launches over the raw points:
+// count (both thresholds at once, so the <min_keep fallback needs no host round trip),
+// then scatter of the centred coordinates.
+// =====================================================================================
+constexpr int GF_THREADS = 256;
+constexpr int GF_ROUNDS  = 8;
+constexpr int GF_TILE    = GF_THREADS * GF_ROUNDS;   // 2048 points per workgroup
+
+struct GfState {
+    unsigned long long total_a, total_b;   // kept with threshold A (offset) / B (fallback)
+    uint32_t use_b;
+    uint32_t aabb[6];                      // ordered-uint32 min xyz / max xyz
+    uint32_t pad;
+};
+
+__global__ __launch_bounds__(GF_THREADS) void gf_count_k(const float* __restrict__ raw, int64_t n,
+                                                         const float* __restrict__ centroid,
+                                                         const float* __restrict__ scal,
+                                                         uint32_t* __restrict__ cnt_a,
+                                                         uint32_t* __restrict__ cnt_b,
+                                                         GfState* __restrict__ st) {
+    __shared__ uint32_t sa[GF_THREADS / 64], sb[GF_THREADS / 64];
+    const float cz = centroid[2];
+    const float thr_a = scal[1], thr_b = scal[2];
+    const int64_t base = (int64_t)blockIdx.x * GF_TILE;
+    uint32_t a = 0, b = 0;
+#pragma unroll
+    for (int r = 0; r < GF_ROUNDS; ++r) {
+        const int64_t i = base + r * GF_THREADS + threadIdx.x;
+        if (i < n) {
+            const float z = raw[3 * i + 2] - cz;
+            a += (z > thr_a);
+            b += (z > thr_b);
+        }
+    }
+    a = wave_reduce_add(a);
+    b = wave_reduce_add(b);
+    if (lane_id() == 0) { sa[wave_id()] = a; sb[wave_id()] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t ta = sa[0] + sa[1] + sa[2] + sa[3];
+        const uint32_t tb = sb[0] + sb[1] + sb[2] + sb[3];
+        cnt_a[blockIdx.x] = ta;
+        cnt_b[blockIdx.x] = tb;
+        if (ta) atomicAdd(&st->total_a, (unsigned long long)ta);
+        if (tb) atomicAdd(&st->total_b, (unsigned long long)tb);
+    }
+}
+
+// picks the threshold (utils/tower_extraction.py:87-89) and publishes the scalars
+__global__ void gf_decide_k(GfState* __restrict__ st, long long min_keep,
+                            const float* __restrict__ centroid, float* __restrict__ scal,
+                            float* __restrict__ out_scalars, int64_t* __restrict__ out_count) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool use_b = (long long)st->total_a < min_keep;
+    st->use_b = use_b ? 1u : 0u;
+    const float thr = use_b ? scal[2] : scal[1];
+    scal[3] = thr;
+    out_scalars[0] = centroid[0];
+    out_scalars[1] = centroid[1];
+    out_scalars[2] = centroid[2];
+    out_scalars[3] = scal[0];
+    out_scalars[4] = thr;
+    out_scalars[5] = use_b ? 1.0f : 0.0f;
+    out_scalars[6] = 0.0f;
+    out_scalars[7] = 0.0f;
+    *out_count = (int64_t)(use_b ? st->total_b : st->total_a);
+    for (int a = 0; a < 3; ++a) { st->aabb[a] = 0xFFFFFFFFu; st->aabb[3 + a] = 0u; }
+}
+
+__global__ __launch_bounds__(GF_THREADS) void gf_scatter_k(
+    const float* __restrict__ raw, int64_t n, const float* __restrict__ centroid,
+    const float* __restrict__ scal, const uint32_t* __restrict__ off_a,
+    const uint32_t* __restrict__ off_b, GfState* __restrict__ st,
+    float* __restrict__ out_points, int32_t* __restrict__ out_index) {
+    __shared__ uint32_t wtot[GF_THREADS / 64];
+    __shared__ uint32_t smm[GF_THREADS / 64][6];
+    const float cx = centroid[0], cy = centroid[1], cz = centroid[2];
+    const float thr = scal[3];
+    const uint32_t block_off = st->use_b ? off_b[blockIdx.x] : off_a[blockIdx.x];
+    const int w = wave_id(), l = lane_id();
+    const int64_t seg = (int64_t)blockIdx.x * GF_TILE + (int64_t)w * (64 * GF_ROUNDS);
+    float px[GF_ROUNDS], py[GF_ROUNDS], pz[GF_ROUNDS];
+    uint32_t pos[GF_ROUNDS];
+    uint32_t run = 0;
+    uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
+    const uint64_t lt = lanemask_lt();
+#pragma unroll
+    for (int r = 0; r < GF_ROUNDS; ++r) {
+        const int64_t i = seg + r * 64 + l;
+        bool keep = false;
+        if (i < n) {
+            px[r] = raw[3 * i + 0] - cx;          // points = raw_points - centroid (float32)
+            py[r] = raw[3 * i + 1] - cy;
+            pz[r] = raw[3 * i + 2] - cz;
+            keep = pz[r] > thr;
+        }
+        const uint64_t m = __ballot(keep);
+        pos[r] = keep ? run + (uint32_t)__popcll(m & lt) : 0xFFFFFFFFu;
+        run += (uint32_t)__popcll(m);
+        if (keep) {
+            const uint32_t kx = f32_ordered(px[r]), ky = f32_ordered(py[r]), kz = f32_ordered(pz[r]);
+            mn[0] = kx < mn[0] ? kx : mn[0]; mx[0] = kx > mx[0] ? kx : mx[0];
+            mn[1] = ky < mn[1] ? ky : mn[1]; mx[1] = ky > mx[1] ? ky : mx[1];
+            mn[2] = kz < mn[2] ? kz : mn[2]; mx[2] = kz > mx[2] ? kz : mx[2];
+        }
+    }
+    if (l == 0) wtot[w] = run;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = wave_reduce_min(mn[a]); mx[a] = wave_reduce_max(mx[a]); }
+    if (l == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { smm[w][a] = mn[a]; smm[w][3 + a] = mx[a]; }
+    }
+    __syncthreads();
+    uint32_t woff = block_off;
+    for (int w2 = 0; w2 < w; ++w2) woff += wtot[w2];
+#pragma unroll
+    for (int r = 0; r < GF_ROUNDS; ++r) {
+        if (pos[r] != 0xFFFFFFFFu) {
+            const int64_t o = (int64_t)woff + pos[r];
+            out_points[3 * o + 0] = px[r];
+            out_points[3 * o + 1] = py[r];
+            out_points[3 * o + 2] = pz[r];
+            if (out_index) out_index[o] = (int32_t)(seg + r * 64 + l);
+        }
+    }
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        uint32_t v = smm[0][a];
+        for (int w2 = 1; w2 < GF_THREADS / 64; ++w2) {
+            const uint32_t o = smm[w2][a];
+            v = (a < 3) ? (o < v ? o : v) : (o > v ? o : v);
+        }
+        if (a < 3) { if (v != 0xFFFFFFFFu) atomicMin(&st->aabb[a], v); }
+        else       { if (v != 0u) atomicMax(&st->aabb[a], v); }
+    }
+}
+
+__global__ void gf_finalize_k(const GfState* __restrict__ st, float* __restrict__ out_aabb) {
+    if (threadIdx.x < 6 && blockIdx.x == 0 && out_aabb) {
+        const uint32_t k = st->aabb[threadIdx.x];
+        const bool empty = (threadIdx.x < 3) ? (k == 0xFFFFFFFFu) : (k == 0u);
+        out_aabb[threadIdx.x] = empty ? 0.0f : f32_unordered(k);
+    }
+}
+
+struct GfWs {
+    float*    centroid;
+    SelWs     sel;
+    GfState*  st;
+    uint32_t *cnt_a, *cnt_b, *scan_ws;
+};
+static void gf_plan(Arena& a, int64_t n, GfWs& w) {
+    const int64_t nb = ceil_div(n > 0 ? n : 1, GF_TILE);
+    w.centroid = a.take<float>(4);
+    sel_plan(a, w.sel);
+    w.st = a.take<GfState>(1);
+    w.cnt_a = a.take<uint32_t>(nb + 8);
+    w.cnt_b = a.take<uint32_t>(nb + 8);
+    w.scan_ws = a.take<uint32_t>(scan_ws_u32(nb));
+}
+
+}  // namespace pch
+
+using namespace pch;
+
+extern "C" size_t pch_mean_seq_f32_ws_bytes(int64_t) { return 256; }
+
+extern "C" int pch_mean_seq_f32(const float* xyz, int64_t n, float* out_centroid, void*, size_t,
+                                void* stream) {
+    prof_begin_call();
+    PCH_REQUIRE(n >= 0 && out_centroid, "bad argument");
+    PCH_REQUIRE(n == 0 || xyz, "null input");
+    PCH_LAUNCH("mean_seq", mean_seq_k, dim3(1), dim3(256), 0, (hipStream_t)stream, xyz, n, out_centroid);
+    return PCH_OK;
+}
+
+extern "C" size_t pch_percentile_f32_ws_bytes(int64_t) {
+    Arena a;
+    SelWs w;
+    sel_plan(a, w);
+    return a.off;
+}
+
+extern "C" int pch_percentile_f32(const float* base, int64_t n, int64_t stride, const float* sub,
+                                  double q_percent, float* out, void* ws, size_t ws_bytes,
+                                  void* stream) {
+    prof_begin_call();
+    hipStream_t s = (hipStream_t)stream;
+    PCH_REQUIRE(n >= 1, "percentile of an empty array (numpy raises IndexError)");
+    PCH_REQUIRE(base && out && ws && stride >= 1, "bad argument");
+    PCH_REQUIRE(q_percent >= 0.0 && q_percent <= 100.0, "Percentiles must be in the range [0, 100]");
+    Arena a(ws, ws_bytes);
+    SelWs w;
+    sel_plan(a, w);
+    if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
+    PCH_TRY(select_percentile(base, n, stride, sub, q_percent, 0.0f, 0.0f, w, s));
+    PCH_HIP_TRY(hipMemcpyAsync(out, w.scal, sizeof(float), hipMemcpyDeviceToDevice, s));
+    return PCH_OK;
+}
+
+extern "C" size_t pch_ground_filter_ws_bytes(int64_t n) {
+    if (n < 0) return 0;
+    Arena a;
+    GfWs w;
+    gf_plan(a, n, w);
+    return a.off;
+}
+
+extern "C" int pch_ground_filter_f32(const float* raw, int64_t n, double pct, float offset,
+                                     float fallback_offset, int64_t min_keep, float* out_points,
+                                     int32_t* out_index, float* out_scalars, int64_t* out_count,
+                                     float* out_aabb, void* ws, size_t ws_bytes, void* stream) {
+    prof_begin_call();
+    hipStream_t s = (hipStream_t)stream;
+    PCH_REQUIRE(n >= 1 && n < (int64_t(1) << 31), "n out of range [1, 2^31) (numpy raises on empty input)");
+    PCH_REQUIRE(raw && out_points && out_scalars && out_count && ws, "null buffer");
+    PCH_REQUIRE(pct >= 0.0 && pct <= 100.0, "Percentiles must be in the range [0, 100]");
+    Arena a(ws, ws_bytes);
+    GfWs w;
+    gf_plan(a, n, w);
+    if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
+    const int64_t nb = ceil_div(n, GF_TILE);
+
+    PCH_LAUNCH("mean_seq", mean_seq_k, dim3(1), dim3(256), 0, s, raw, n, w.centroid);
+    PCH_TRY(select_percentile(raw + 2, n, 3, w.centroid + 2, pct, offset, fallback_offset, w.sel, s));
+    PCH_HIP_TRY(hipMemsetAsync(w.st, 0, sizeof(GfState), s));
+    PCH_LAUNCH("gf_count", gf_count_k, dim3((unsigned)nb), dim3(GF_THREADS), 0, s, raw, n,
+               (const float*)w.centroid, (const float*)w.sel.scal, w.cnt_a, w.cnt_b, w.st);
+    PCH_LAUNCH("gf_decide", gf_decide_k, dim3(1), dim3(64), 0, s, w.st, (long long)min_keep,
+               (const float*)w.centroid, w.sel.scal, out_scalars, out_count);
+    PCH_TRY(scan_exclusive_u32(w.cnt_a, w.cnt_a, nb, w.scan_ws, nullptr, s));
+    PCH_TRY(scan_exclusive_u32(w.cnt_b, w.cnt_b, nb, w.scan_ws, nullptr, s));
+    PCH_LAUNCH("gf_scatter", gf_scatter_k, dim3((unsigned)nb), dim3(GF_THREADS), 0, s, raw, n,
+               (const float*)w.centroid, (const float*)w.sel.scal, (const uint32_t*)w.cnt_a,
+               (const uint32_t*)w.cnt_b, w.st, out_points, out_index);
+    PCH_LAUNCH("gf_finalize", gf_finalize_k, dim3(1), dim3(64), 0, s, (const GfState*)w.st, out_aabb);
+    return PCH_OK;
+}

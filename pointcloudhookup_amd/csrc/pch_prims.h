@@ -1,0 +1,21 @@
+// Device-wide primitives shared by the stage kernels: exclusive scan and LSD radix sort.
+#pragma once
+#include "pch_common.h"
+
+namespace pch {
+
+// ---- exclusive scan of uint32 (n < 2^31).  `out` may alias `in`.
+// ws: scan_ws_u32(n) uint32 words.  total (optional, device) receives the grand total.
+size_t scan_ws_u32(int64_t n);
+int scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* ws,
+                       uint32_t* total, hipStream_t s);
+
+// ---- stable LSD radix sort of (uint64 key, uint32 value) pairs on key bits [0, nbits).
+// Buffers ping-pong between (k0,v0) and (k1,v1); the sorted result lands in buffer
+// radix_sort_result_buffer(nbits) (0 or 1).  ws: radix_ws_u32(n) uint32 words.
+size_t radix_ws_u32(int64_t n);
+int    radix_sort_result_buffer(int nbits);
+int radix_sort_pairs(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, int64_t n,
+                     int nbits, uint32_t* ws, hipStream_t s);
+
+}  // namespace pch

@@ -1,0 +1,228 @@
+"""Tensor-level operators: PyTorch-ROCm tensors in, C-ABI calls underneath.
+
+torch is used for device memory, streams and (in tiles.py) torch.distributed only; all
+arithmetic happens in libpch_hip.so.  Every function requires CUDA(HIP) tensors and raises
+if the extension or a GPU is missing - there is no CPU fallback here by design.
+
+One function per reference library call:
+  voxel_downsample  <- open3d voxel_down_sample per chunk   ui/import_PC.py:8-13,45-58
+  mean_seq_f32      <- np.mean(raw, axis=0)                  utils/tower_extraction.py:63
+  percentile_f32    <- np.percentile(z, 25)                  utils/tower_extraction.py:83
+  ground_filter     <- centring + percentile filter          utils/tower_extraction.py:63-64,82-89
+  dbscan            <- chunked sklearn DBSCAN + label offset utils/tower_extraction.py:96-117
+  segment_by_label  <- per-label boolean masks               utils/tower_extraction.py:125,131-134
+"""
+from __future__ import annotations
+
+import threading
+
+import torch
+
+from . import _lib
+
+_tls = threading.local()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _need_cuda(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError(f"{name} must be a CUDA/HIP tensor (no CPU fallback in the product path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _workspace(nbytes, device):
+    """Grow-only per-thread, per-device scratch buffer."""
+    cache = getattr(_tls, "ws", None)
+    if cache is None:
+        cache = _tls.ws = {}
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    buf = cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        cache[key] = None
+        buf = None
+        buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+        cache[key] = buf
+    return buf
+
+
+def release_workspace():
+    _tls.ws = {}
+
+
+def set_profiling(enable):
+    _lib.lib().pch_set_profiling(1 if enable else 0)
+
+
+def get_profile():
+    return _lib.get_profile()
+
+
+# ---------------------------------------------------------------------------- stage A
+def voxel_downsample(xyz, voxel_size, chunk_size=0):
+    """Per-chunk voxel-grid downsample.  Returns (idx int32 [m,3], mean f64 [m,3],
+    count int32 [m], chunk_offsets int64 [nchunks+1]); rows grouped by chunk, sorted by
+    (ix,iy,iz) inside a chunk.  Synchronises (reads m)."""
+    L = _lib.lib()
+    xyz = _need_cuda(xyz, torch.float64, "xyz").reshape(-1, 3)
+    n = xyz.shape[0]
+    dev = xyz.device
+    cs = int(chunk_size) if chunk_size and chunk_size > 0 else max(n, 1)
+    nchunks = max(1, -(-n // cs))
+    with torch.cuda.device(dev):
+        idx = torch.empty((n, 3), dtype=torch.int32, device=dev)
+        mean = torch.empty((n, 3), dtype=torch.float64, device=dev)
+        count = torch.empty((n,), dtype=torch.int32, device=dev)
+        offs = torch.zeros((nchunks + 1,), dtype=torch.int64, device=dev)
+        m_dev = torch.zeros((1,), dtype=torch.int64, device=dev)
+        nb = L.pch_voxel_downsample_ws_bytes(n, cs)
+        ws = _workspace(nb, dev)
+        _lib.check(L.pch_voxel_downsample_f64(_ptr(xyz), n, float(voxel_size), cs, _ptr(idx), _ptr(mean),
+                                              _ptr(count), _ptr(offs), _ptr(m_dev), _ptr(ws), ws.numel(),
+                                              _stream()))
+        m = int(m_dev.item())
+    return idx[:m], mean[:m], count[:m], offs
+
+
+def las_scale(XYZ_i32, scales, offsets):
+    """laspy scaled view: int32 [n,3] -> float64 [n,3] (X*scale+offset)."""
+    import ctypes as C
+    L = _lib.lib()
+    X = _need_cuda(XYZ_i32, torch.int32, "XYZ").reshape(-1, 3)
+    out = torch.empty(X.shape, dtype=torch.float64, device=X.device)
+    sc = (C.c_double * 3)(*[float(v) for v in scales])
+    of = (C.c_double * 3)(*[float(v) for v in offsets])
+    with torch.cuda.device(X.device):
+        _lib.check(L.pch_las_scale_i32_f64(_ptr(X), X.shape[0], C.cast(sc, C.c_void_p),
+                                           C.cast(of, C.c_void_p), _ptr(out), _stream()))
+    return out
+
+
+def las_unscale(xyz_f64, scales, offsets):
+    """laspy coordinate setter: float64 [n,3] -> int32 [n,3] (rint((v-offset)/scale))."""
+    import ctypes as C
+    L = _lib.lib()
+    x = _need_cuda(xyz_f64, torch.float64, "xyz").reshape(-1, 3)
+    out = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    sc = (C.c_double * 3)(*[float(v) for v in scales])
+    of = (C.c_double * 3)(*[float(v) for v in offsets])
+    with torch.cuda.device(x.device):
+        _lib.check(L.pch_las_unscale_f64_i32(_ptr(x), x.shape[0], C.cast(sc, C.c_void_p),
+                                             C.cast(of, C.c_void_p), _ptr(out), _stream()))
+    return out
+
+
+# ---------------------------------------------------------------------------- stage B
+def cast_f32(x_f64):
+    L = _lib.lib()
+    x = _need_cuda(x_f64, torch.float64, "x")
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(L.pch_cast_f64_f32(_ptr(x), x.numel(), _ptr(out), _stream()))
+    return out
+
+
+def mean_seq_f32(xyz):
+    """np.mean(xyz, axis=0) for C-order float32 [n,3], bit exact.  Returns float32 [3]."""
+    L = _lib.lib()
+    xyz = _need_cuda(xyz, torch.float32, "xyz").reshape(-1, 3)
+    out = torch.empty((3,), dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        nb = L.pch_mean_seq_f32_ws_bytes(xyz.shape[0])
+        ws = _workspace(nb, xyz.device)
+        _lib.check(L.pch_mean_seq_f32(_ptr(xyz), xyz.shape[0], _ptr(out), _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
+def percentile_f32(values, q_percent, sub=None):
+    """np.percentile(values - sub, q) for a float32 vector (any stride).  Returns float32 [1]."""
+    L = _lib.lib()
+    if not values.is_cuda or values.dtype != torch.float32 or values.dim() != 1:
+        raise TypeError("values must be a 1-D float32 CUDA tensor")
+    n = values.shape[0]
+    stride = values.stride(0) if n > 1 else 1
+    out = torch.empty((1,), dtype=torch.float32, device=values.device)
+    with torch.cuda.device(values.device):
+        nb = L.pch_percentile_f32_ws_bytes(n)
+        ws = _workspace(nb, values.device)
+        _lib.check(L.pch_percentile_f32(values.data_ptr(), n, stride, _ptr(sub), float(q_percent),
+                                        _ptr(out), _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
+def ground_filter(raw, pct=25.0, offset=3.0, fallback_offset=1.0, min_keep=1000, want_index=True):
+    """Fused stage B on float32 [n,3].  Returns dict(points [n_f,3] f32 (centred, file
+    order), index int32 [n_f] | None, centroid f32[3] (host np), base, threshold,
+    used_fallback, aabb (host, 6 floats), count).  Synchronises (reads n_f)."""
+    L = _lib.lib()
+    raw = _need_cuda(raw, torch.float32, "raw").reshape(-1, 3)
+    n = raw.shape[0]
+    dev = raw.device
+    with torch.cuda.device(dev):
+        out_points = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        out_index = torch.empty((n,), dtype=torch.int32, device=dev) if want_index else None
+        scal = torch.zeros((16,), dtype=torch.float32, device=dev)     # [0:8] scalars, [8:14] aabb
+        cnt = torch.zeros((1,), dtype=torch.int64, device=dev)
+        nb = L.pch_ground_filter_ws_bytes(n)
+        ws = _workspace(nb, dev)
+        _lib.check(L.pch_ground_filter_f32(_ptr(raw), n, float(pct), float(offset), float(fallback_offset),
+                                           int(min_keep), _ptr(out_points), _ptr(out_index), _ptr(scal),
+                                           _ptr(cnt), scal.data_ptr() + 32, _ptr(ws), ws.numel(), _stream()))
+        host = scal.cpu().numpy()           # one D2H copy, synchronises the stream
+        nf = int(cnt.item())
+    return dict(points=out_points[:nf], index=None if out_index is None else out_index[:nf],
+                centroid=host[0:3].copy(), base=host[3], threshold=host[4],
+                used_fallback=bool(host[5] != 0.0), aabb=host[8:14].copy(), count=nf)
+
+
+# ---------------------------------------------------------------------------- stage C
+def dbscan(xyz, eps=8.0, min_samples=80, chunk_size=50000, aabb=None, want_core=False):
+    """Chunked exact DBSCAN on float32 [n,3].  Returns (labels int32 [n], core uint8 [n] | None,
+    nclusters int).  Synchronises."""
+    import ctypes as C
+    L = _lib.lib()
+    xyz = _need_cuda(xyz, torch.float32, "xyz").reshape(-1, 3)
+    n = xyz.shape[0]
+    dev = xyz.device
+    with torch.cuda.device(dev):
+        labels = torch.empty((n,), dtype=torch.int32, device=dev)
+        core = torch.empty((n,), dtype=torch.uint8, device=dev) if want_core else None
+        ncl = torch.zeros((1,), dtype=torch.int32, device=dev)
+        nb = L.pch_dbscan_ws_bytes(n)
+        ws = _workspace(nb, dev)
+        box = None
+        if aabb is not None:
+            box = (C.c_float * 6)(*[float(v) for v in aabb])
+        _lib.check(L.pch_dbscan_f32(_ptr(xyz), n, float(eps), int(min_samples), int(chunk_size),
+                                    None if box is None else C.cast(box, C.c_void_p), _ptr(labels),
+                                    _ptr(core), _ptr(ncl), _ptr(ws), ws.numel(), _stream()))
+        k = int(ncl.item())
+    return labels, core, k
+
+
+# ---------------------------------------------------------------------------- stage D0
+def segment_by_label(labels, xyz, nclusters):
+    """Returns (perm int32 [n], offsets int64 [K+1], stats f32 [K,8] (min xyz, max xyz, 0, 0))."""
+    L = _lib.lib()
+    labels = _need_cuda(labels, torch.int32, "labels")
+    xyz = _need_cuda(xyz, torch.float32, "xyz").reshape(-1, 3)
+    n = labels.shape[0]
+    dev = labels.device
+    K = int(nclusters)
+    with torch.cuda.device(dev):
+        perm = torch.empty((n,), dtype=torch.int32, device=dev)
+        offsets = torch.zeros((K + 1,), dtype=torch.int64, device=dev)
+        stats = torch.zeros((max(K, 1), 8), dtype=torch.float32, device=dev)
+        nb = L.pch_segment_by_label_ws_bytes(n, K)
+        ws = _workspace(nb, dev)
+        _lib.check(L.pch_segment_by_label(_ptr(labels), _ptr(xyz), n, K, _ptr(perm), _ptr(offsets),
+                                          _ptr(stats), _ptr(ws), ws.numel(), _stream()))
+    return perm, offsets, stats[:K]

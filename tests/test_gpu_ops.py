@@ -1,0 +1,226 @@
+"""Parity of every C-ABI operator against the CPU oracle on the same seeded inputs
+(bit-exact for indices, counts, labels and for every float the reference computes)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dbscan as odb
+from oracle import ground_filter as ogf
+from oracle import voxel as ovx
+from pointcloudhookup_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+OFFSET = synth.GLOBAL_OFFSET
+
+
+def _dev(a, cuda, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(cuda)
+
+
+# ------------------------------------------------------------------------------ stage A
+@pytest.mark.parametrize("n,voxel,chunk", [(1, 0.1, 0), (5, 0.5, 2), (1000, 0.5, 0), (1000, 0.5, 300),
+                                           (20000, 0.2, 7000), (200000, 0.1, 50000),
+                                           (300000, 0.2, 0)])
+def test_voxel_matches_oracle(cuda, n, voxel, chunk):
+    rng = np.random.default_rng(n)
+    pts = rng.random((n, 3)) * [60.0, 25.0, 8.0] + OFFSET
+    pts[: n // 3] = np.round(pts[: n // 3], 1)              # many exact duplicates / shared voxels
+    idx, mean, count, offs = ops.voxel_downsample(_dev(pts, cuda), voxel, chunk)
+    ridx, rmean, rcount, roffs = ovx.voxel_down_sample_chunked(pts, voxel, chunk if chunk else n)
+    assert idx.shape[0] == ridx.shape[0]
+    np.testing.assert_array_equal(offs.cpu().numpy(), roffs)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)          # voxel indices bit exact
+    np.testing.assert_array_equal(count.cpu().numpy(), rcount)
+    np.testing.assert_array_equal(mean.cpu().numpy(), rmean)        # in-order f64 sums: bit exact
+
+
+def test_voxel_single_voxel_and_negative_coords(cuda):
+    pts = np.array([[-1.0, -2.0, -3.0], [-1.01, -2.01, -3.01], [-0.99, -1.99, -2.99]])
+    idx, mean, count, _ = ops.voxel_downsample(_dev(pts, cuda), 5.0, 0)
+    ridx, rmean, rcount = ovx.voxel_down_sample(pts, 5.0)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_array_equal(mean.cpu().numpy(), rmean)
+    np.testing.assert_array_equal(count.cpu().numpy(), rcount)
+
+
+def test_voxel_too_small_raises(cuda):
+    from pointcloudhookup_amd._lib import PchError
+    pts = np.array([[0.0, 0.0, 0.0], [1.0e7, 0.0, 0.0]])
+    with pytest.raises(PchError):
+        ops.voxel_downsample(_dev(pts, cuda), 1e-3, 0)          # Open3D: voxel_size is too small
+
+
+def test_las_scale_roundtrip(cuda):
+    rng = np.random.default_rng(3)
+    X = rng.integers(-2**31, 2**31 - 1, size=(5000, 3), dtype=np.int64).astype(np.int32)
+    sc, of = [0.001, 0.001, 0.01], [437000.0, 3139000.0, -12.5]
+    out = ops.las_scale(_dev(X, cuda), sc, of).cpu().numpy()
+    ref = np.stack([ovx.las_scaled(X[:, a], sc[a], of[a]) for a in range(3)], axis=1)
+    np.testing.assert_array_equal(out, ref)
+    back = ops.las_unscale(_dev(ref, cuda), sc, of).cpu().numpy()
+    refb = np.stack([ovx.las_unscale(ref[:, a], sc[a], of[a]) for a in range(3)], axis=1)
+    np.testing.assert_array_equal(back, refb)
+
+
+# ------------------------------------------------------------------------------ stage B
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 4096, 4097, 100000, 1500000])
+def test_mean_seq_bit_exact(cuda, n):
+    rng = np.random.default_rng(n)
+    raw = (rng.random((n, 3)) * [1000, 100, 30] + OFFSET).astype(np.float32)
+    got = ops.mean_seq_f32(_dev(raw, cuda)).cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.uint32), np.mean(raw, axis=0).view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 9, 1000, 1001, 65537, 1000003])
+@pytest.mark.parametrize("q", [25, 0, 100, 50, 73.5])
+def test_percentile_bit_exact(cuda, n, q):
+    rng = np.random.default_rng(n * 7 + int(q))
+    z = rng.normal(0, 5, n).astype(np.float32)
+    if n > 8:
+        z[rng.integers(0, n, n // 4)] = np.float32(1.25)     # heavy duplicates around the rank
+    pts = np.zeros((n, 3), np.float32)
+    pts[:, 2] = z
+    t = _dev(pts, cuda)
+    got = ops.percentile_f32(t[:, 2], q).cpu().numpy()[0]
+    ref = np.percentile(z, q)
+    assert np.float32(got).view(np.uint32) == np.float32(ref).view(np.uint32), (got, ref)
+
+
+def test_percentile_nan_and_sub(cuda):
+    z = np.array([1.0, np.nan, 3.0, 2.0, 5.0], np.float32)
+    got = ops.percentile_f32(_dev(z, cuda), 25).cpu().numpy()[0]
+    assert np.isnan(got) and np.isnan(np.percentile(z, 25))
+    z = np.random.default_rng(0).normal(80, 9, 5001).astype(np.float32)
+    c = torch.tensor([77.125], dtype=torch.float32, device=cuda)
+    got = ops.percentile_f32(_dev(z, cuda), 25, sub=c).cpu().numpy()[0]
+    ref = np.percentile(z - np.float32(77.125), 25)
+    assert np.float32(got).view(np.uint32) == np.float32(ref).view(np.uint32)
+
+
+@pytest.mark.parametrize("n,kind,offset", [(50000, "corridor", True), (50000, "corridor", False),
+                                           (200000, "uniform", True), (1000000, "corridor", True),
+                                           (3000, "flat", False)])
+def test_ground_filter_matches_numpy(cuda, n, kind, offset):
+    if kind == "flat":       # fewer than 1000 survivors at +3.0 -> the +1.0 fallback
+        rng = np.random.default_rng(5)
+        pts = np.column_stack([rng.uniform(0, 50, n), rng.uniform(0, 50, n), rng.normal(0, 0.7, n)])
+        pts[:40, 2] += 10.0
+    else:
+        pts = synth.corridor_numpy(n, seed=synth.SEED0 + 1, kind=kind, offset=offset, towers=3)
+    raw = pts.astype(np.float32)
+    ref = ogf.ground_filter(raw)
+    got = ops.ground_filter(_dev(raw, cuda))
+    np.testing.assert_array_equal(got["centroid"].view(np.uint32), ref["centroid"].view(np.uint32))
+    assert np.float32(got["base"]).view(np.uint32) == ref["base"].view(np.uint32)
+    assert np.float32(got["threshold"]).view(np.uint32) == ref["threshold"].view(np.uint32)
+    assert got["used_fallback"] == ref["used_fallback"]
+    assert got["count"] == len(ref["filtered"])
+    np.testing.assert_array_equal(got["points"].cpu().numpy().view(np.uint32),
+                                  ref["filtered"].view(np.uint32))
+    np.testing.assert_array_equal(got["index"].cpu().numpy(), np.flatnonzero(ref["keep"]))
+    if got["count"]:
+        f = ref["filtered"]
+        np.testing.assert_array_equal(got["aabb"], np.concatenate([f.min(0), f.max(0)]))
+
+
+# ------------------------------------------------------------------------------ stage C
+def _blobs(rng, n, k, spread, sigma, clutter):
+    per = (n - clutter) // k
+    parts = [rng.normal(rng.uniform(-spread, spread, 3), sigma, (per, 3)) for _ in range(k)]
+    parts.append(rng.uniform(-spread * 1.3, spread * 1.3, (n - per * k, 3)))
+    X = np.vstack(parts).astype(np.float32)
+    return X[rng.permutation(len(X))]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_dbscan_small_vs_sklearn_rule(cuda, seed):
+    rng = np.random.default_rng(seed)
+    X = _blobs(rng, 700, 3, 6.0, 1.0, 200)
+    ref, rcore = odb.dbscan_fit_sklearn(X, 1.0, 8)
+    labels, core, k = ops.dbscan(_dev(X, cuda), 1.0, 8, 0, want_core=True)
+    np.testing.assert_array_equal(core.cpu().numpy(), rcore)
+    np.testing.assert_array_equal(labels.cpu().numpy(), ref)
+    assert k == ref.max() + 1
+
+
+@pytest.mark.parametrize("n,eps,ms,chunk", [(5000, 8.0, 80, 0), (5000, 8.0, 80, 1200),
+                                            (30000, 8.0, 80, 10000), (30000, 2.0, 10, 0),
+                                            (12000, 0.5, 3, 5000), (4000, 8.0, 1, 0),
+                                            (3000, 1e-3, 2, 0), (3000, 1e3, 5, 0)])
+def test_dbscan_chunked_vs_oracle(cuda, oracle_clib, n, eps, ms, chunk):
+    rng = np.random.default_rng(n + ms)
+    k = 4
+    per = n // (k + 1)
+    parts = [rng.normal([rng.uniform(0, 300), rng.uniform(0, 100), 22.0], [2.5, 2.5, 9.0], (per, 3))
+             for _ in range(k)]
+    parts.append(np.column_stack([rng.uniform(0, 300, n - k * per), rng.uniform(0, 100, n - k * per),
+                                  rng.uniform(0, 30, n - k * per)]))
+    X = np.vstack(parts).astype(np.float32)
+    X = X[rng.permutation(n)]
+    ref = odb.dbscan_chunked(X, eps, ms, chunk, fit="c")
+    labels, _, kk = ops.dbscan(_dev(X, cuda), eps, ms, chunk)
+    np.testing.assert_array_equal(labels.cpu().numpy(), ref)
+    assert kk == (ref.max() + 1 if (ref >= 0).any() else 0)
+
+
+def test_dbscan_reference_chunk_vs_sklearn(cuda):
+    """One full 50 000-row chunk shaped like the reference's input, checked against the real
+    sklearn call of utils/tower_extraction.py:107-112."""
+    rng = np.random.default_rng(1)
+    X = np.vstack([rng.normal([c, 50, 22], [3, 3, 10], (15000, 3)) for c in (100, 400, 700)]
+                  + [np.column_stack([rng.uniform(0, 1000, 5000), rng.uniform(0, 100, 5000),
+                                      rng.uniform(0, 30, 5000)])]).astype(np.float32)
+    X = X[rng.permutation(len(X))]
+    ref, rcore = odb.dbscan_fit_sklearn(X, 8.0, 80)
+    labels, core, k = ops.dbscan(_dev(X, cuda), 8.0, 80, 50000, want_core=True)
+    np.testing.assert_array_equal(core.cpu().numpy(), rcore)
+    np.testing.assert_array_equal(labels.cpu().numpy(), ref)
+
+
+def test_dbscan_edge_cases(cuda):
+    one = np.zeros((1, 3), np.float32)
+    labels, core, k = ops.dbscan(_dev(one, cuda), 8.0, 1, 0, want_core=True)
+    assert labels.cpu().tolist() == [0] and k == 1 and core.cpu().tolist() == [1]
+    labels, _, k = ops.dbscan(_dev(one, cuda), 8.0, 2, 0)
+    assert labels.cpu().tolist() == [-1] and k == 0
+    same = np.ones((500, 3), np.float32) * 7.5                      # all coincident
+    labels, _, k = ops.dbscan(_dev(same, cuda), 0.5, 80, 0)
+    assert k == 1 and (labels.cpu().numpy() == 0).all()
+    labels, _, k = ops.dbscan(_dev(same, cuda), 0.5, 80, 100)       # 5 chunks -> ids 0..4
+    np.testing.assert_array_equal(labels.cpu().numpy(), np.repeat(np.arange(5), 100))
+    empty = torch.zeros((0, 3), dtype=torch.float32, device=cuda)
+    labels, _, k = ops.dbscan(empty, 8.0, 80, 0)
+    assert labels.numel() == 0 and k == 0
+
+
+def test_dbscan_border_tie_takes_smallest_cluster(cuda):
+    # two dense lines, one border point exactly between them within eps of both
+    a = np.column_stack([np.linspace(0, 1, 30), np.zeros(30), np.zeros(30)])
+    b = np.column_stack([np.linspace(3.2, 4.2, 30), np.zeros(30), np.zeros(30)])
+    mid = np.array([[2.1, 0.0, 0.0]])
+    X = np.vstack([b, mid, a]).astype(np.float32)                   # cluster 0 = b (seen first)
+    ref, _ = odb.dbscan_fit_sklearn(X, 1.15, 8)
+    labels, _, _ = ops.dbscan(_dev(X, cuda), 1.15, 8, 0)
+    np.testing.assert_array_equal(labels.cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------------------ stage D0
+def test_segment_by_label(cuda):
+    rng = np.random.default_rng(9)
+    n, K = 100000, 37
+    labels = rng.integers(-1, K, n).astype(np.int32)
+    labels[labels == 5] = -1                                        # an empty cluster
+    xyz = rng.normal(0, 10, (n, 3)).astype(np.float32)
+    perm, offs, stats = ops.segment_by_label(_dev(labels, cuda), _dev(xyz, cuda), K)
+    perm, offs, stats = perm.cpu().numpy(), offs.cpu().numpy(), stats.cpu().numpy()
+    for k in range(K):
+        rows = perm[offs[k]:offs[k + 1]]
+        np.testing.assert_array_equal(rows, np.flatnonzero(labels == k))
+        if len(rows):
+            np.testing.assert_array_equal(stats[k, :3], xyz[rows].min(0))
+            np.testing.assert_array_equal(stats[k, 3:6], xyz[rows].max(0))
+    np.testing.assert_array_equal(perm[offs[K]:], np.flatnonzero(labels == -1))
