@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: ground filter + tower clustering on a synthetic corridor.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--kind corridor|uniform]
+
+One "step" = one pass of stages B + C + D0 (float32 centroid/centring, percentile height
+filter, chunked exact DBSCAN, label grouping) over one resident float32 [P,3] tile per GPU.
+Prints ONE JSON line (rank 0).  N > 1 is launched by torch.distributed.run, one rank per GPU;
+every rank owns an independent tile (weak scaling) and the only collective is the label /
+cluster-table reconciliation of pointcloudhookup_amd/tiles.py.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+EPS, MIN_POINTS, CHUNK = 8.0, 80, 50000
+
+
+def knn_tile_bytes(points, eps, chunk):
+    """SURVEY.md 8(d) tile model for the radius-count kernel: cubic cells of side eps, every
+    query cell stages its <=27 occupied neighbour cells once (12 B/point) and writes one
+    4-byte word per point.  Returns (bytes, cell occupancy histogram summary)."""
+    import torch
+    n = points.shape[0]
+    if n == 0:
+        return 0, {}
+    lo = points.min(dim=0).values
+    c = torch.floor((points - lo).double() / eps).long()
+    dims = c.max(dim=0).values + 3
+    ck = torch.arange(n, device=points.device) // chunk
+    key = ((ck * dims[2] + c[:, 2] + 1) * dims[1] + c[:, 1] + 1) * dims[0] + c[:, 0] + 1
+    uniq, cnt = torch.unique(key, return_counts=True)
+    total = torch.zeros((), dtype=torch.int64, device=points.device)
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                nk = uniq + (dz * dims[1] + dy) * dims[0] + dx
+                pos = torch.searchsorted(uniq, nk).clamp(max=uniq.numel() - 1)
+                hit = uniq[pos] == nk
+                total += (cnt[pos] * hit).sum()
+    occ = dict(cells=int(uniq.numel()), max=int(cnt.max()), mean=float(cnt.double().mean()))
+    return int(12 * int(total) + 4 * n), occ
+
+
+def algorithmic_bytes(name, N, NF):
+    """Compulsory HBM bytes of one launch of kernel `name` ("kernels" table)."""
+    table = {
+        "mean_seq": 12 * N, "sel_hist0": 4 * N, "sel_hist1": 4 * N, "sel_hist2": 4 * N,
+        "sel_next": 4 * N, "gf_count": 4 * N, "gf_scatter": 12 * N + 12 * NF,
+        "db_keys": 24 * NF, "db_gather": 44 * NF, "db_cells": 24 * NF, "db_label": 33 * NF,
+        "radix_hist": 8 * NF, "radix_scatter": 24 * NF, "scan_reduce": 4 * NF, "scan_apply": 8 * NF,
+        "seg_keys": 16 * NF, "seg_perm": 8 * NF, "seg_stats": 16 * NF,
+        "db_cellbox": 17 * NF, "db_compmin": 17 * NF,
+    }
+    return table.get(name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=100_000_000)
+    ap.add_argument("--kind", default="corridor", choices=["corridor", "uniform"])
+    ap.add_argument("--offset", action="store_true", help="add the EPSG:4547-scale global offset")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pointcloudhookup_amd import ops, pipeline, synth, tiles
+
+    rank, world, local = tiles.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    N = int(args.points)
+    seed = synth.SEED0 + 2 + rank
+    raw = synth.corridor_torch(N, seed=seed, kind=args.kind, offset=args.offset, device=dev,
+                               dtype=torch.float32)
+    torch.cuda.synchronize()
+
+    def step():
+        cl = pipeline.cluster_points(raw, EPS, MIN_POINTS, CHUNK)
+        if world > 1:
+            off, total, table, owner = tiles.reconcile(cl["nclusters"], cl["stats"])
+            cl["label_offset"], cl["global_clusters"] = off, total
+        return cl
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        cl = step()
+    barrier()
+    ops.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cl = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ops.get_profile()
+    ops.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    NF = int(cl["ground"]["count"])
+    K = int(cl["nclusters"])
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = N * world * args.steps / elapsed / 1e6
+
+    # ---- per-kernel times from the library's own hipEvents (timed region only)
+    kernels = sorted(((n, ms / max(c, 1), c, ms / args.steps) for n, ms, c in prof),
+                     key=lambda r: -r[3])
+    gpu_ms = sum(r[3] for r in kernels)
+    knn_bytes, occ = knn_tile_bytes(cl["ground"]["points"], EPS, CHUNK)
+    dom = kernels[0]
+
+    def roof(name, avg_ms):
+        if name in ("db_core", "db_union", "db_border"):
+            b = knn_bytes
+        else:
+            b = algorithmic_bytes(name, N, NF)
+        if b is None or avg_ms <= 0:
+            return None
+        a = b / (avg_ms * 1e-3) / 1e9
+        return dict(kernel=name, bound="hbm", achieved=round(a, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(a / HBM_PEAK_GBS, 4), traffic=None, avg_ms=round(avg_ms, 4),
+                    bytes_per_launch=int(b))
+
+    roofline = roof(dom[0], dom[1]) or dict(kernel=dom[0], bound="hbm", achieved=None,
+                                            peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None)
+    knn = next((roof(r[0], r[1]) for r in kernels if r[0] == "db_core"), None)
+    tr_path = os.path.join(ROOT, "profiles", "traffic.json")   # PMC passes, see profiles/README.md
+    if os.path.exists(tr_path):
+        try:
+            tr = json.load(open(tr_path))
+            for r in (roofline, knn):
+                if r and tr.get("points") == N and r["kernel"] in tr.get("kernels", {}):
+                    r["traffic"] = tr["kernels"][r["kernel"]]
+        except Exception:
+            pass
+
+    out = {
+        "metric": "Mpts/s ground-filter+tower-cluster, 100 M-pt corridor; % HBM roofline on kNN",
+        "value": round(value, 2), "unit": "Mpts/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 (filter) + f64 (distance predicate)",
+        "data": "synthetic",
+        "config": {"workload": f"{N / 1e6:g} M-pt synthetic {args.kind}, ground filter + chunked "
+                               f"DBSCAN(eps={EPS:g}, min_samples={MIN_POINTS}, chunk={CHUNK}) + label "
+                               "grouping, 1 tile per GPU (BASELINE configs[2])",
+                   "points_per_gpu": N, "frame": "global-offset" if args.offset else "local",
+                   "filtered_points": NF, "clusters": K, "seed": seed},
+        "roofline": roofline,
+        "knn_kernel": knn,
+        "gpu_kernel_ms_per_step": round(gpu_ms, 3),
+        "kernels": [dict(name=r[0], avg_ms=round(r[1], 4), launches_per_step=r[2] / args.steps,
+                         ms_per_step=round(r[3], 4)) for r in kernels[:12]],
+        "knn_cell_occupancy": occ,
+    }
+
+    # ---- CPU baseline: the reference's own library calls (numpy + sklearn) on host cores
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle import ground_filter as ogf, dbscan as odb
+            host = raw.cpu().numpy()
+            t0 = time.perf_counter()
+            gf = ogf.ground_filter(host)
+            t_filter = time.perf_counter() - t0
+            filt = gf["filtered"]
+            nch = (len(filt) + CHUNK - 1) // CHUNK
+            fit = "sklearn"
+            try:
+                import sklearn  # noqa: F401
+            except Exception:
+                fit = "c"
+            gpu_labels = cl["labels"].cpu().numpy()
+            parity = (len(filt) == NF)
+            done, t_cl = 0, 0.0
+            stride = max(1, nch // 6)
+            for ci in range(0, nch, stride):
+                chunk = filt[ci * CHUNK:(ci + 1) * CHUNK]
+                t1 = time.perf_counter()
+                ref, _ = odb._FITS[fit](chunk, EPS, MIN_POINTS)
+                t_cl += time.perf_counter() - t1
+                done += 1
+                g = gpu_labels[ci * CHUNK:(ci + 1) * CHUNK].astype(np.int64)
+                base = g[g >= 0].min() if (g >= 0).any() else 0
+                parity = parity and np.array_equal(np.where(g >= 0, g - base, -1), ref)
+                if t_filter + t_cl > args.cpu_budget_s and done >= 2:
+                    break
+            est = t_filter + (t_cl / max(done, 1)) * nch
+            out["cpu_baseline"] = {
+                "value": round(N / est / 1e6, 4), "unit": "Mpts/s", "cores": os.cpu_count(),
+                "kind": "port",
+                "sample": f"numpy mean/percentile/mask on all {N} pts ({t_filter:.2f} s) + "
+                          f"{'sklearn DBSCAN(ball_tree, n_jobs=-1)' if fit == 'sklearn' else 'oracle C all-pairs DBSCAN'}"
+                          f" on {done} of {nch} 50k-chunks ({t_cl:.2f} s), clustering time extrapolated "
+                          f"x{nch / max(done, 1):.1f}",
+                "parity_on_sample": bool(parity)}
+        except Exception as e:                                   # never lose the GPU line
+            out["cpu_baseline"] = {"value": None, "unit": "Mpts/s", "cores": os.cpu_count(),
+                                   "kind": "port", "sample": f"failed: {e}"}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

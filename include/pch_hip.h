@@ -103,7 +103,8 @@ int pch_percentile_f32(const float* base, int64_t n, int64_t stride, const float
  * raw          [n,3] float32
  * out_points   [n,3] float32 capacity; first *out_count rows = points[keep] (file order)
  * out_index    [n]   int32 (may be NULL): original row of each kept point
- * out_scalars  [8]   float32: centroid xyz, base, threshold, used_fallback(0/1), 0, 0
+ * out_scalars  [8]   float32: centroid xyz, base, threshold, used_fallback(0/1),
+ *                    (float)count kept at `offset` (exact below 2^24), 0
  * out_count    [1]   int64
  * out_aabb     [6]   float32 (may be NULL): min xyz, max xyz of the kept points
  */
@@ -153,8 +154,8 @@ int pch_segment_by_label(const int32_t* labels, const float* xyz, int64_t n,
 /* --------------------------------------------------------- profiling helpers
  * Last-call timings recorded with hipEvents on the caller's stream when
  * pch_set_profiling(1): fills up to `cap` (name, total ms, launch count) triples for the
- * kernels of the last pch_* call made by this thread.  Returns the number of entries.
- * (synchronises) */
+ * kernels launched by this thread's pch_* calls since the previous pch_get_profile /
+ * pch_set_profiling call.  Returns the number of entries.  (synchronises) */
 void pch_set_profiling(int enable);
 int  pch_get_profile(int cap, char names[][48], float* ms, int* launches);
 

@@ -62,16 +62,17 @@ struct Arena {
 
 // ---------------------------------------------------------------- profiling
 // When enabled every PCH_LAUNCH is bracketed by hipEvents recorded on the launch stream.
-void prof_begin_call();                       // clears this thread's record list
+void prof_begin_call();                       // (records accumulate until collected)
 bool prof_enabled();
 void prof_pre(const char* name, hipStream_t s);
 void prof_post(hipStream_t s);
 
 #define PCH_LAUNCH(name, kernel, grid, block, shmem, stream, ...)                  \
     do {                                                                           \
-        if (::pch::prof_enabled()) ::pch::prof_pre(name, stream);                  \
+        const bool _prof = ::pch::prof_enabled();                                  \
+        if (_prof) ::pch::prof_pre(name, stream);                                  \
         hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);       \
-        if (::pch::prof_enabled()) ::pch::prof_post(stream);                       \
+        if (_prof) ::pch::prof_post(stream);                                       \
         hipError_t _le = hipGetLastError();                                        \
         if (_le != hipSuccess) {                                                   \
             ::pch::set_error("launch %s failed: %s", name, hipGetErrorString(_le)); \

@@ -35,9 +35,16 @@ static hipEvent_t take_event() {
     return e;
 }
 
-bool prof_enabled() { return g_prof_on; }
 
-void prof_begin_call() {
+// Records accumulate over pch_* calls until pch_get_profile() collects them (bench.py reads
+// one whole step at once); a cap keeps a caller that never collects from growing forever.
+constexpr size_t PROF_MAX_RECORDS = 16384;
+
+void prof_begin_call() {}
+
+bool prof_enabled() { return g_prof_on && g_recs.size() < PROF_MAX_RECORDS; }
+
+static void prof_clear() {
     for (auto& r : g_recs) {
         g_pool.push_back(r.e0);
         g_pool.push_back(r.e1);
@@ -72,7 +79,7 @@ int pch_device_count(void) {
 
 void pch_set_profiling(int enable) {
     pch::g_prof_on = enable != 0;
-    if (!enable) pch::prof_begin_call();
+    pch::prof_clear();
 }
 
 int pch_get_profile(int cap, char names[][48], float* ms, int* launches) {
@@ -103,6 +110,7 @@ int pch_get_profile(int cap, char names[][48], float* ms, int* launches) {
         ms[n] = total[k];
         if (launches) launches[n] = count[k];
     }
+    prof_clear();
     return n;
 }
 

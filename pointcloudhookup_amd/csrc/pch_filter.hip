@@ -300,7 +300,7 @@ __global__ void gf_decide_k(GfState* __restrict__ st, long long min_keep,
     out_scalars[3] = scal[0];
     out_scalars[4] = thr;
     out_scalars[5] = use_b ? 1.0f : 0.0f;
-    out_scalars[6] = 0.0f;
+    out_scalars[6] = (float)st->total_a;      // kept at the first threshold (exact below 2^24)
     out_scalars[7] = 0.0f;
     *out_count = (int64_t)(use_b ? st->total_b : st->total_a);
     for (int a = 0; a < 3; ++a) { st->aabb[a] = 0xFFFFFFFFu; st->aabb[3 + a] = 0u; }

@@ -108,8 +108,9 @@ __global__ __launch_bounds__(VX_THREADS) void vx_starts_k(const uint64_t* __rest
                                                           int64_t n, uint32_t* __restrict__ seg_start) {
     const int64_t i = (int64_t)blockIdx.x * VX_THREADS + threadIdx.x;
     if (i >= n) return;
-    if (i == 0 || keys[i] != keys[i - 1]) seg_start[vid[i]] = (uint32_t)i;
-    if (i == n - 1) seg_start[vid[i] + 1] = (uint32_t)n;
+    const bool head = (i == 0 || keys[i] != keys[i - 1]);
+    if (head) seg_start[vid[i]] = (uint32_t)i;      // vid = exclusive scan of the head flags
+    if (i == n - 1) seg_start[vid[i] + (head ? 1u : 0u)] = (uint32_t)n;   // == seg_start[m]
 }
 
 // one thread per voxel: sequential float64 sum in point order (AccumulatedPoint::AddPoint),

@@ -180,7 +180,8 @@ def ground_filter(raw, pct=25.0, offset=3.0, fallback_offset=1.0, min_keep=1000,
         nf = int(cnt.item())
     return dict(points=out_points[:nf], index=None if out_index is None else out_index[:nf],
                 centroid=host[0:3].copy(), base=host[3], threshold=host[4],
-                used_fallback=bool(host[5] != 0.0), aabb=host[8:14].copy(), count=nf)
+                used_fallback=bool(host[5] != 0.0), count_at_offset=int(host[6]),
+                aabb=host[8:14].copy(), count=nf)
 
 
 # ---------------------------------------------------------------------------- stage C

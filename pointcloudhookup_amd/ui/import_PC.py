@@ -1,0 +1,87 @@
+"""Drop-in for the reference's ``ui/import_PC.py`` (process_chunk, run_voxel_downsampling).
+
+Same names, defaults, log texts, progress values and output file as
+/root/reference/ui/import_PC.py:8-69.  The per-chunk Open3D voxel grids are computed on the
+GPU by ``pch_voxel_downsample_f64`` (all chunks in one pass, each with its own grid origin,
+cross-chunk duplicates kept - exactly the reference's chunk loop); LAS decode/encode
+arithmetic (X*scale+offset, rint((v-offset)/scale)) also runs on the device.
+
+Output order differs from Open3D's (hash-map iteration order there, sorted by voxel index
+here); the set of output points is the same.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable
+
+import numpy as np
+
+DEVICE = os.environ.get("PCH_DEVICE", "cuda:0")
+
+
+def process_chunk(points_chunk, voxel_size):
+    """Voxel-downsample one chunk: (n,3) array -> (m,3) float64 voxel means
+    (reference ui/import_PC.py:8-13)."""
+    import torch
+    from .. import ops
+    pts = np.ascontiguousarray(np.asarray(points_chunk).astype(np.float64)).reshape(-1, 3)
+    if pts.shape[0] == 0:
+        return np.zeros((0, 3), dtype=np.float64)
+    _, mean, _, _ = ops.voxel_downsample(torch.from_numpy(pts).to(DEVICE), float(voxel_size), 0)
+    return mean.cpu().numpy()
+
+
+def run_voxel_downsampling(
+    input_path: str,
+    output_path: str,
+    voxel_size: float = 0.1,
+    chunk_size: int = 1000000,
+    progress_callback: Callable[[int], None] = None,
+    log_callback: Callable[[str], None] = None
+):
+    if not os.path.exists(input_path):
+        raise FileNotFoundError(f"输入文件不存在: {os.path.abspath(input_path)}")
+
+    os.makedirs(os.path.dirname(output_path), exist_ok=True)
+
+    import torch
+    from .. import las as _las
+    from .. import ops
+
+    data = _las.read(input_path)
+    total_points = len(data)
+
+    if log_callback:
+        log_callback(f"📂 原始点数: {total_points}")
+        log_callback(f"✨ 开始下采样（voxel_size={voxel_size}, chunk_size={chunk_size}）")
+
+    hdr = data.header
+    dev = torch.device(DEVICE)
+    if total_points:
+        XYZ = torch.from_numpy(data.XYZ).to(dev)
+        xyz = ops.las_scale(XYZ, hdr.scales, hdr.offsets)            # chunk.x/.y/.z  (:47-48)
+        del XYZ
+        _, mean, _, offs = ops.voxel_downsample(xyz, float(voxel_size), int(chunk_size))
+        del xyz
+        out_XYZ = ops.las_unscale(mean, hdr.scales, hdr.offsets).cpu().numpy()   # :61-63
+        n_out = int(mean.shape[0])
+        del mean
+    else:
+        out_XYZ = np.zeros((0, 3), np.int32)
+        n_out = 0
+
+    # the reference reports per chunk while it loops (:45-58); here all chunks are done
+    for i, start in enumerate(range(0, total_points, chunk_size)):
+        end = min(start + chunk_size, total_points)
+        if log_callback:
+            log_callback(f"✅ 已完成第{i+1}块：{end - start} 点")
+        if progress_callback:
+            progress_callback(int((end / total_points) * 100))
+
+    _las.write(output_path, _las.LasHeader(point_format=hdr.point_format, version=hdr.version,
+                                           scales=hdr.scales, offsets=hdr.offsets), out_XYZ)
+    ops.release_workspace()
+
+    if log_callback:
+        log_callback(f"✅ 下采样完成，输出点数: {n_out}")
+        log_callback(f"📁 保存至：{output_path}")

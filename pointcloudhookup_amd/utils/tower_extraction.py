@@ -1,0 +1,188 @@
+"""Drop-in for the reference's ``utils/tower_extraction.py`` (== ``ui/ui/tower_extraction.py``).
+
+Same module-level names, keyword defaults, return value, log texts, progress milestones and
+side-effect files as /root/reference/utils/tower_extraction.py:20-285; the arithmetic runs on
+the GPU through libpch_hip.so (height filter, chunked DBSCAN, label grouping) with only the
+per-cluster box fit, LAS/xlsx writing and the Python bookkeeping on the host.  Like the
+reference this function never raises: failures are logged and what exists is returned.
+
+Module knobs (not in the reference): ``OBB_EXTENT_ORDER`` ("unsorted" | "trimesh_sorted",
+env PCH_OBB_EXTENT_ORDER) selects the extent convention of the box fit, ``DEVICE`` the GPU.
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+
+import numpy as np
+
+OBB_EXTENT_ORDER = os.environ.get("PCH_OBB_EXTENT_ORDER", "unsorted")
+DEVICE = os.environ.get("PCH_DEVICE", "cuda:0")
+CHUNK_SIZE = 50000                                     # utils/tower_extraction.py:96
+
+
+def extract_towers(
+        input_las_path,
+        progress_callback=None,
+        log_callback=None,
+        eps=8.0,
+        min_points=80,
+        aspect_ratio_threshold=0.8,
+        min_height=15.0,
+        max_width=50.0,
+        min_width=8,
+        duplicate_threshold=30.0
+):
+    """Tower extraction with the reference's call surface (utils/tower_extraction.py:20-240)."""
+    tower_obbs = []
+    tower_rows = []
+
+    def log(msg):
+        (log_callback or print)(msg)
+
+    def progress(value):
+        if progress_callback:
+            progress_callback(value)
+
+    output_dir = Path("output_towers")
+    output_dir.mkdir(exist_ok=True)
+
+    # ---- read + float32 cast (reference :57-76)
+    try:
+        log("📂 读取点云文件...")
+        progress(5)
+        import torch
+        from .. import las as _las
+        from .. import ops, pipeline
+        data = _las.read(input_las_path)
+        dev = torch.device(DEVICE)
+        XYZ = torch.from_numpy(data.XYZ).to(dev)
+        raw = ops.cast_f32(ops.las_scale(XYZ, data.header.scales, data.header.offsets))
+        del XYZ
+        header_info = {"scales": data.header.scales, "offsets": data.header.offsets,
+                       "point_format": data.header.point_format, "version": data.header.version}
+        log(f"✅ 点云读取完成，总点数: {raw.shape[0]}")
+    except Exception as e:
+        log(f"⚠️ 文件读取失败: {str(e)}")
+        return tower_obbs
+
+    # ---- percentile height filter (reference :79-93)
+    try:
+        log("🔍 执行高度过滤...")
+        progress(10)
+        if raw.shape[0] == 0:
+            raise IndexError("index -1 is out of bounds for axis 0 with size 0")
+        gf = ops.ground_filter(raw, 25.0, 3.0, 1.0, 1000, want_index=False)
+        header_info["centroid"] = gf["centroid"]
+        if gf["used_fallback"]:
+            log(f"✅ 高度过滤完成，保留点数: {gf['count_at_offset']}")
+            log("⚠️ 过滤后点数太少，尝试降低过滤阈值")
+        else:
+            log(f"✅ 高度过滤完成，保留点数: {gf['count']}")
+    except Exception as e:
+        log(f"⚠️ 高度过滤失败: {str(e)}")
+        return tower_obbs
+    del raw
+
+    # ---- chunked clustering (reference :96-122); all chunks run in one device pass
+    filtered = gf["points"]
+    n_f = int(filtered.shape[0])
+    n_chunks = (n_f + CHUNK_SIZE - 1) // CHUNK_SIZE
+    log("\n=== 开始聚类处理 ===")
+    progress(20)
+    clusters = dict(ground=gf, nclusters=0)
+    try:
+        if n_f:
+            labels, _, k = ops.dbscan(filtered, eps, min_points, CHUNK_SIZE, aabb=gf["aabb"])
+            perm, offsets, stats = ops.segment_by_label(labels, filtered, k)
+            clusters.update(labels=labels, nclusters=k, perm=perm, offsets=offsets, stats=stats)
+        for i in range(n_chunks):
+            log(f"处理分块 {i + 1}/{n_chunks} ({min(CHUNK_SIZE, n_f - i * CHUNK_SIZE)}点)")
+            progress(20 + int(50 * (i + 1) / n_chunks))
+    except Exception as e:
+        # the reference loses single chunks (:118-119); one fused pass loses them together
+        log(f"⚠️ 分块聚类失败（块0-{max(n_chunks - 1, 0)}）: {str(e)}")
+
+    # ---- tower detection + de-dup (reference :125-218)
+    k = int(clusters["nclusters"])
+    log(f"\n=== 开始杆塔检测（候选簇：{k}个） ===")
+    progress(75)
+    centroid = gf["centroid"]
+
+    def accept(t):
+        label = t["label"]
+        tower_obbs.append({"center": t["center"], "rotation": t["rotation"], "extent": t["extent"],
+                           "height": t["height"], "width": t["width"],
+                           "north_angle": t["north_angle"], "points": t["points"]})
+        tower_rows.append({"ID": f"tower_{label}", "经度": t["center"][0], "纬度": t["center"][1],
+                           "海拔高度": t["center"][2], "杆塔高度": t["height"],
+                           "北方向偏角": t["north_angle"], "宽度": t["width"],
+                           "长宽比": t["aspect_ratio"]})
+        original_points = t["points"] + centroid                       # float32, reference :205
+        _save_tower_las(original_points, None, header_info, output_dir / f"tower_{label}.las", log)
+        log(f"✅ 杆塔{label}: {t['height']:.1f}m高 | {t['width']:.1f}m宽 | 中心坐标{t['center']}")
+        progress(75 + int(15 * (label + 1) / max(k, 1)))
+
+    pipeline.tower_table(clusters, aspect_ratio_threshold, min_height, max_width, min_width,
+                         duplicate_threshold, OBB_EXTENT_ORDER, log=log, on_accept=accept)
+
+    # ---- xlsx (reference :221-231)
+    if tower_rows:
+        try:
+            import pandas as pd
+            output_excel_path = "towers_info.xlsx"
+            pd.DataFrame(tower_rows).to_excel(output_excel_path, index=False)
+            log(f"\n✅ 杆塔信息已保存到: {output_excel_path}")
+            log(f"检测到杆塔数量: {len(tower_obbs)}个")
+        except Exception as e:
+            log(f"⚠️ 保存Excel失败: {str(e)}")
+    else:
+        log("\n⚠️ 未检测到任何杆塔，不生成Excel文件")
+
+    log("\n=== 清理内存 ===")
+    del filtered, clusters, gf
+    ops.release_workspace()
+    progress(100)
+    log("✅ 杆塔提取完成")
+    return tower_obbs
+
+
+def _save_tower_las(points, colors, header_info, output_path, log_callback=None):
+    """Per-tower LAS with the input's point format / version / scales / offsets
+    (reference :243-262); coordinates are re-quantised like laspy's x/y/z setters."""
+    try:
+        from .. import las as _las
+        pts = np.asarray(points)
+        sc, of = np.asarray(header_info["scales"], float), np.asarray(header_info["offsets"], float)
+        XYZ = np.round((pts.astype(np.float64) - of) / sc).astype(np.int32)
+        hdr = _las.LasHeader(point_format=header_info["point_format"], version=header_info["version"],
+                             scales=sc, offsets=of)
+        _las.write(str(output_path), hdr, XYZ)
+        if log_callback:
+            log_callback(f"保存成功：{output_path}")
+    except Exception as e:
+        if log_callback:
+            log_callback(f"⚠️ 保存失败 {output_path}: {str(e)}")
+
+
+def create_obb_geometries(tower_obbs):
+    """Open3D line sets of the tower boxes (reference :265-279); needs open3d, imported lazily."""
+    import open3d as o3d
+    geometries = []
+    for tower in tower_obbs:
+        try:
+            box = o3d.geometry.OrientedBoundingBox()
+            box.center = tower['center']
+            box.extent = tower['extent']
+            box.R = tower['rotation']
+            mesh = o3d.geometry.LineSet.create_from_oriented_bounding_box(box)
+            mesh.paint_uniform_color([1, 0, 0])
+            geometries.append(mesh)
+        except Exception:
+            continue
+    return geometries
+
+
+def extract_towers_optimized(*args, **kwargs):
+    """Alias kept for callers of the older name (reference :283-285)."""
+    return extract_towers(*args, **kwargs)
