@@ -86,6 +86,9 @@ int pch_cast_f64_f32(const double* in, int64_t count, float* out, void* stream);
 size_t pch_mean_seq_f32_ws_bytes(int64_t n);
 int pch_mean_seq_f32(const float* xyz, int64_t n, float* out_centroid,
                      void* ws, size_t ws_bytes, void* stream);
+/* same result from one workgroup adding element by element (O(n) serial; kept only to
+ * cross-check the parallel algorithm above) */
+int pch_mean_seq_serial_f32(const float* xyz, int64_t n, float* out_centroid, void* stream);
 
 /* np.percentile(v, q) (method 'linear', numpy 2.x float32 semantics) of the strided
  * float32 column v[i] = base[i*stride] - (sub ? *sub : 0).

@@ -36,6 +36,7 @@ _SIGS = {
     "pch_cast_f64_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pch_mean_seq_f32_ws_bytes": (_sz, [_i64]),
     "pch_mean_seq_f32": (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "pch_mean_seq_serial_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pch_percentile_f32_ws_bytes": (_sz, [_i64]),
     "pch_percentile_f32": (C.c_int, [_vp, _i64, _i64, _vp, _f64, _vp, _vp, _sz, _vp]),
     "pch_ground_filter_ws_bytes": (_sz, [_i64]),

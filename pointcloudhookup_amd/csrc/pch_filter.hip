@@ -6,11 +6,180 @@
 namespace pch {
 
 // =====================================================================================
-// B1: np.mean(raw, axis=0) on a C-order (n,3) float32 array == sequential float32 running
-// sum per column, then one float32 division by float32(n).
-// v0 implementation: one workgroup streams tiles through LDS, lanes 0..2 carry the three
-// (inherently ordered) accumulation chains.
+// B1: np.mean(raw, axis=0) on a C-order (n,3) float32 array == SEQUENTIAL float32 running
+// sum per column, then one float32 division by float32(n)  (utils/tower_extraction.py:63).
+//
+// The sequential sum is reproduced bit for bit, in parallel:
+// while the running sum s = sigma*m*u keeps its sign and stays inside one binade
+// (m in [2^23,2^24), u = ulp(s)), fl(s + a) = sigma*(m + rne(sigma*a/u))*u, i.e. the sum is
+// INTEGER addition of per-element increments d_i = rne(a_i/u) that do not depend on m (unless
+// a_i/u has fraction exactly 1/2: a "tie").  So for a block of points and a candidate binade
+// E the whole block collapses to two integers (sum of positive / negative increments):
+//   ms_summary_k : one wave per 1024-point block, all 24 useful candidates E = emax+1..emax+24
+//                  (E <= emax: an element as large as s -> handled by the slow path;
+//                   E >  emax+24: every increment is 0, s cannot move)
+//   ms_walk_k    : one wave per column walks the blocks 64 at a time: prefix-sums the
+//                  increments for the current E, certifies per block that no prefix can leave
+//                  the binade (m - neg - 1 >= 2^23, m + pos + 1 < 2^24) and that the block has
+//                  no tie; the first block that fails is added element by element (exact by
+//                  construction) and the walk resumes with the new s.
+// Order inside a certified block is irrelevant, so the result equals the sequential sum.
 // =====================================================================================
+constexpr int MSB       = 1024;    // points per summary block (one wave, 16 per lane)
+constexpr int MS_PER    = 16;
+constexpr int MS_CAND   = 24;
+constexpr int MS_WAVES  = 4;
+constexpr uint32_t MS_NONFINITE = 1u, MS_ALLZERO = 2u;
+
+struct MsHdr { int emax; uint32_t tie; uint32_t flags; uint32_t pad; };
+
+__global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __restrict__ xyz, int64_t n,
+                                                             int64_t nb, MsHdr* __restrict__ hdr,
+                                                             long long* __restrict__ apos,
+                                                             long long* __restrict__ aneg) {
+    const int64_t blk = (int64_t)blockIdx.x * MS_WAVES + wave_id();
+    if (blk >= nb) return;
+    const int l = lane_id();
+    const int64_t p0 = blk * MSB;
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        float a[MS_PER];
+#pragma unroll
+        for (int i = 0; i < MS_PER; ++i) {
+            const int64_t p = p0 + i * 64 + l;
+            a[i] = (p < n) ? xyz[3 * p + c] : 0.0f;
+        }
+        uint32_t mx = 0;
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < MS_PER; ++i) {
+            const uint32_t u = __float_as_uint(a[i]) & 0x7FFFFFFFu;
+            mx = u > mx ? u : mx;
+            bad |= (u >= 0x7F800000u);
+        }
+        mx = wave_reduce_max(mx);
+        const bool nonfinite = __ballot(bad) != 0;
+        const int ef = (int)(mx >> 23);
+        const int emax = (ef > 0 ? ef : 1) - 127;
+        int pos[MS_CAND], neg[MS_CAND];
+#pragma unroll
+        for (int j = 0; j < MS_CAND; ++j) { pos[j] = 0; neg[j] = 0; }
+        uint32_t tie = 0;
+        if (!nonfinite && mx != 0) {
+#pragma unroll
+            for (int i = 0; i < MS_PER; ++i) {
+                float x = ldexpf(a[i], 22 - emax);             // a / ulp(2^(emax+1)), |x| < 2^23
+#pragma unroll
+                for (int j = 0; j < MS_CAND; ++j) {
+                    const float r = rintf(x);                   // round half to even
+                    tie |= (fabsf(x - r) == 0.5f) ? (1u << j) : 0u;
+                    const int ri = (int)r;
+                    pos[j] += ri > 0 ? ri : 0;
+                    neg[j] += ri < 0 ? -ri : 0;
+                    x *= 0.5f;
+                }
+            }
+        }
+        uint32_t tie_all = tie;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tie_all |= __shfl_xor(tie_all, o, 64);
+        const int64_t row = ((int64_t)c * nb + blk);
+        if (l == 0) {
+            MsHdr h;
+            h.emax = emax;
+            h.tie = tie_all;
+            h.flags = (nonfinite ? MS_NONFINITE : 0u) | (mx == 0 ? MS_ALLZERO : 0u);
+            h.pad = 0;
+            hdr[row] = h;
+        }
+#pragma unroll
+        for (int j = 0; j < MS_CAND; ++j) {
+            const long long tp = wave_reduce_add((long long)pos[j]);
+            const long long tn = wave_reduce_add((long long)neg[j]);
+            if (l == j) { apos[row * MS_CAND + j] = tp; aneg[row * MS_CAND + j] = tn; }
+        }
+    }
+}
+
+__device__ __forceinline__ long long ms_readlane64(long long v, int lane) {
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xFFFFFFFFll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), lane);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// one wave per column
+__global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, int64_t n, int64_t nb,
+                                                const MsHdr* __restrict__ hdr,
+                                                const long long* __restrict__ apos,
+                                                const long long* __restrict__ aneg,
+                                                float* __restrict__ out) {
+    __shared__ float stage[MSB];
+    const int c = blockIdx.x;
+    const int l = lane_id();
+    uint32_t sb = 0;                                   // bits of the running sum (+0.0)
+    int64_t b = 0;
+    while (b < nb) {
+        const uint32_t ef = (sb >> 23) & 0xFFu;
+        if (ef == 255u && (sb & 0x7FFFFFu)) break;     // NaN is absorbing
+        const bool s_inf = ef == 255u;
+        const bool s_norm = ef >= 1u && ef <= 254u;
+        const bool s_neg = (sb >> 31) != 0;
+        const int E = (int)ef - 127;
+        const int64_t bb = b + l;
+        const bool valid = bb < nb;
+        MsHdr h;
+        h.emax = 0; h.tie = 0; h.flags = MS_ALLZERO; h.pad = 0;
+        if (valid) h = hdr[(int64_t)c * nb + bb];
+        const int j = E - h.emax - 1;
+        // 0 = no change, 1 = table increment, 2 = must be added element by element
+        int cls;
+        if (!valid || (h.flags & MS_ALLZERO)) cls = 0;
+        else if (s_inf) cls = (h.flags & MS_NONFINITE) ? 2 : 0;
+        else if (!s_norm || (h.flags & MS_NONFINITE) || j < 0) cls = 2;
+        else if (j >= MS_CAND) cls = 0;
+        else cls = ((h.tie >> j) & 1u) ? 2 : 1;
+        long long up = 0, dn = 0;
+        if (cls == 1) {
+            const int64_t at = ((int64_t)c * nb + bb) * MS_CAND + j;
+            const long long p = apos[at], q = aneg[at];
+            up = s_neg ? q : p;                        // increments of |s|
+            dn = s_neg ? p : q;
+        }
+        const long long net = up - dn;
+        const long long incl = wave_scan_incl(net);
+        const long long m0 = (long long)((sb & 0x7FFFFFu) | 0x800000u);
+        const long long m_in = m0 + incl - net;
+        const bool ok = cls == 0 || (cls == 1 && m_in + up + 1 < (1ll << 24) && m_in - dn - 1 >= (1ll << 23));
+        const unsigned long long fail = __ballot(valid && !ok);
+        const int f = fail ? (int)__builtin_ctzll(fail) : 64;
+        if (f > 0 && s_norm) {
+            const long long m1 = m0 + ms_readlane64(incl, f - 1);
+            sb = (sb & 0xFF800000u) | ((uint32_t)m1 & 0x7FFFFFu);   // same sign, same binade
+        }
+        if (!fail) { b += 64; continue; }
+        // exact element-by-element pass over block b+f
+        const int64_t blk = b + f;
+        const int64_t p0 = blk * MSB;
+        const int cnt = (int)((n - p0) < MSB ? (n - p0) : MSB);
+        for (int i = l; i < cnt; i += 64) stage[i] = xyz[3 * (p0 + i) + c];
+        __syncthreads();
+        float s = __uint_as_float(sb);
+        int i = 0;
+        for (; i + 8 <= cnt; i += 8) {
+            const float a0 = stage[i], a1 = stage[i + 1], a2 = stage[i + 2], a3 = stage[i + 3],
+                        a4 = stage[i + 4], a5 = stage[i + 5], a6 = stage[i + 6], a7 = stage[i + 7];
+            s = s + a0; s = s + a1; s = s + a2; s = s + a3;
+            s = s + a4; s = s + a5; s = s + a6; s = s + a7;
+        }
+        for (; i < cnt; ++i) s = s + stage[i];
+        __syncthreads();
+        sb = __builtin_amdgcn_readfirstlane(__float_as_uint(s));
+        b = blk + 1;
+    }
+    if (l == 0) out[c] = __uint_as_float(sb) / (float)n;    // n == 0 -> 0/0 = NaN like numpy
+}
+
+// single-workgroup reference variant (kept for cross-checking the parallel algorithm)
 constexpr int MS_TILE = 4096;   // points per LDS tile (48 KiB)
 
 __global__ __launch_bounds__(256) void mean_seq_k(const float* __restrict__ xyz, int64_t n,
@@ -36,7 +205,27 @@ __global__ __launch_bounds__(256) void mean_seq_k(const float* __restrict__ xyz,
         }
         __syncthreads();
     }
-    if (threadIdx.x < 3) out[threadIdx.x] = s / (float)n;   // n == 0 -> 0/0 = NaN like numpy
+    if (threadIdx.x < 3) out[threadIdx.x] = s / (float)n;
+}
+
+struct MsWs {
+    MsHdr*     hdr;
+    long long *apos, *aneg;
+};
+static void ms_plan(Arena& a, int64_t n, MsWs& w) {
+    const int64_t nb = ceil_div(n > 0 ? n : 1, MSB);
+    w.hdr = a.take<MsHdr>(3 * nb);
+    w.apos = a.take<long long>(3 * nb * MS_CAND);
+    w.aneg = a.take<long long>(3 * nb * MS_CAND);
+}
+static int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, hipStream_t s) {
+    const int64_t nb = ceil_div(n > 0 ? n : 1, MSB);
+    if (n > 0)
+        PCH_LAUNCH("mean_summary", ms_summary_k, dim3((unsigned)ceil_div(nb, MS_WAVES)), dim3(64 * MS_WAVES),
+                   0, s, xyz, n, nb, w.hdr, w.apos, w.aneg);
+    PCH_LAUNCH("mean_walk", ms_walk_k, dim3(3), dim3(64), 0, s, xyz, n, n > 0 ? nb : 0,
+               (const MsHdr*)w.hdr, (const long long*)w.apos, (const long long*)w.aneg, out);
+    return PCH_OK;
 }
 
 // =====================================================================================
@@ -385,6 +574,7 @@ __global__ void gf_finalize_k(const GfState* __restrict__ st, float* __restrict_
 
 struct GfWs {
     float*    centroid;
+    MsWs      ms;
     SelWs     sel;
     GfState*  st;
     uint32_t *cnt_a, *cnt_b, *scan_ws;
@@ -392,6 +582,7 @@ struct GfWs {
 static void gf_plan(Arena& a, int64_t n, GfWs& w) {
     const int64_t nb = ceil_div(n > 0 ? n : 1, GF_TILE);
     w.centroid = a.take<float>(4);
+    ms_plan(a, n, w.ms);
     sel_plan(a, w.sel);
     w.st = a.take<GfState>(1);
     w.cnt_a = a.take<uint32_t>(nb + 8);
@@ -403,14 +594,31 @@ static void gf_plan(Arena& a, int64_t n, GfWs& w) {
 
 using namespace pch;
 
-extern "C" size_t pch_mean_seq_f32_ws_bytes(int64_t) { return 256; }
+extern "C" size_t pch_mean_seq_f32_ws_bytes(int64_t n) {
+    if (n < 0) return 0;
+    Arena a;
+    MsWs w;
+    ms_plan(a, n, w);
+    return a.off;
+}
 
-extern "C" int pch_mean_seq_f32(const float* xyz, int64_t n, float* out_centroid, void*, size_t,
-                                void* stream) {
+extern "C" int pch_mean_seq_f32(const float* xyz, int64_t n, float* out_centroid, void* ws,
+                                size_t ws_bytes, void* stream) {
+    prof_begin_call();
+    PCH_REQUIRE(n >= 0 && out_centroid && ws, "bad argument");
+    PCH_REQUIRE(n == 0 || xyz, "null input");
+    Arena a(ws, ws_bytes);
+    MsWs w;
+    ms_plan(a, n, w);
+    if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
+    return mean_seq_launch(xyz, n, out_centroid, w, (hipStream_t)stream);
+}
+
+extern "C" int pch_mean_seq_serial_f32(const float* xyz, int64_t n, float* out_centroid, void* stream) {
     prof_begin_call();
     PCH_REQUIRE(n >= 0 && out_centroid, "bad argument");
     PCH_REQUIRE(n == 0 || xyz, "null input");
-    PCH_LAUNCH("mean_seq", mean_seq_k, dim3(1), dim3(256), 0, (hipStream_t)stream, xyz, n, out_centroid);
+    PCH_LAUNCH("mean_seq_serial", mean_seq_k, dim3(1), dim3(256), 0, (hipStream_t)stream, xyz, n, out_centroid);
     return PCH_OK;
 }
 
@@ -461,7 +669,7 @@ extern "C" int pch_ground_filter_f32(const float* raw, int64_t n, double pct, fl
     if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
     const int64_t nb = ceil_div(n, GF_TILE);
 
-    PCH_LAUNCH("mean_seq", mean_seq_k, dim3(1), dim3(256), 0, s, raw, n, w.centroid);
+    PCH_TRY(mean_seq_launch(raw, n, w.centroid, w.ms, s));
     PCH_TRY(select_percentile(raw + 2, n, 3, w.centroid + 2, pct, offset, fallback_offset, w.sel, s));
     PCH_HIP_TRY(hipMemsetAsync(w.st, 0, sizeof(GfState), s));
     PCH_LAUNCH("gf_count", gf_count_k, dim3((unsigned)nb), dim3(GF_THREADS), 0, s, raw, n,

@@ -130,12 +130,16 @@ def cast_f32(x_f64):
     return out
 
 
-def mean_seq_f32(xyz):
-    """np.mean(xyz, axis=0) for C-order float32 [n,3], bit exact.  Returns float32 [3]."""
+def mean_seq_f32(xyz, serial=False):
+    """np.mean(xyz, axis=0) for C-order float32 [n,3], bit exact.  Returns float32 [3].
+    ``serial`` selects the one-workgroup element-by-element variant (cross-check only)."""
     L = _lib.lib()
     xyz = _need_cuda(xyz, torch.float32, "xyz").reshape(-1, 3)
     out = torch.empty((3,), dtype=torch.float32, device=xyz.device)
     with torch.cuda.device(xyz.device):
+        if serial:
+            _lib.check(L.pch_mean_seq_serial_f32(_ptr(xyz), xyz.shape[0], _ptr(out), _stream()))
+            return out
         nb = L.pch_mean_seq_f32_ws_bytes(xyz.shape[0])
         ws = _workspace(nb, xyz.device)
         _lib.check(L.pch_mean_seq_f32(_ptr(xyz), xyz.shape[0], _ptr(out), _ptr(ws), ws.numel(), _stream()))

@@ -75,6 +75,65 @@ def test_mean_seq_bit_exact(cuda, n):
     np.testing.assert_array_equal(got.view(np.uint32), np.mean(raw, axis=0).view(np.uint32))
 
 
+def _mean_cases():
+    rng = np.random.default_rng(42)
+    n = 700000
+    yield "local", (rng.random((n, 3)) * [10000, 100, 30]).astype(np.float32)
+    yield "zero_mean", rng.normal(0, 100, (n, 3)).astype(np.float32)
+    yield "integers_ties", rng.integers(-50, 50, (n, 3)).astype(np.float32)
+    yield "halves_ties", (rng.integers(0, 4000, (n, 3)) * 0.5).astype(np.float32)
+    yield "quarter_lattice", (rng.integers(12556000, 12557000, (n, 3)) * 0.25).astype(np.float32)
+    yield "constant", np.full((n, 3), 3.14e6, np.float32)
+    yield "tiny", (rng.random((n, 3)) * 1e-40).astype(np.float32)
+    yield "mixed_scale", (rng.random((n, 3)) * (10.0 ** rng.integers(-6, 7, (n, 1)))).astype(np.float32)
+    a = (rng.random((n, 3)) * 100).astype(np.float32)
+    a[123456, 1] = 1e30
+    yield "outlier", a
+    a = (rng.random((n, 3)) * 100).astype(np.float32)
+    a[5000, 0] = np.inf
+    a[600000, 0] = -np.inf
+    a[77, 2] = np.nan
+    a[300000, 1] = np.inf
+    yield "nonfinite", a
+    a = np.zeros((n, 3), np.float32)
+    a[400000:] = (rng.random((n - 400000, 3)) - 0.3).astype(np.float32)
+    yield "leading_zeros", a
+    yield "negative", (-(rng.random((n, 3)) * [1000, 100, 30] + OFFSET)).astype(np.float32)
+    yield "sign_flip_walk", (np.sin(np.arange(3 * n).reshape(n, 3) * 1e-3) * 50).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", [c[0] for c in _mean_cases()])
+def test_mean_seq_distributions(cuda, name):
+    raw = dict(_mean_cases())[name]
+    t = _dev(raw, cuda)
+    with np.errstate(all="ignore"):
+        ref = np.mean(raw, axis=0)
+    got = ops.mean_seq_f32(t).cpu().numpy()
+    ser = ops.mean_seq_f32(t, serial=True).cpu().numpy()
+    np.testing.assert_array_equal(ser.view(np.uint32) & 0x7FFFFFFF if np.isnan(ref).any() else ser.view(np.uint32),
+                                  ref.view(np.uint32) & 0x7FFFFFFF if np.isnan(ref).any() else ref.view(np.uint32))
+    if np.isnan(ref).any():
+        assert (np.isnan(got) == np.isnan(ref)).all()
+        np.testing.assert_array_equal(got[~np.isnan(ref)], ref[~np.isnan(ref)])
+    else:
+        np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_mean_seq_stagnation_40m(cuda):
+    """float32 running sums that stop growing (ulp/2 > element): 40 M rows at EPSG:4547 scale."""
+    n = 40_000_000
+    g = torch.Generator(device=cuda)
+    g.manual_seed(7)
+    t = torch.rand((n, 3), generator=g, device=cuda, dtype=torch.float32)
+    t = t * torch.tensor([1000.0, 100.0, 30.0], device=cuda) + torch.tensor(OFFSET, device=cuda,
+                                                                          dtype=torch.float32)
+    raw = t.cpu().numpy()
+    ref = np.mean(raw, axis=0)
+    got = ops.mean_seq_f32(t).cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert abs(float(ref[1]) - 3139050.0) > 1e5        # the reference's centroid really is that far off
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 9, 1000, 1001, 65537, 1000003])
 @pytest.mark.parametrize("q", [25, 0, 100, 50, 73.5])
 def test_percentile_bit_exact(cuda, n, q):
