@@ -55,7 +55,7 @@ def knn_tile_bytes(points, eps, chunk):
 def algorithmic_bytes(name, N, NF):
     """Compulsory HBM bytes of one launch of kernel `name` ("kernels" table)."""
     table = {
-        "mean_seq": 12 * N, "sel_hist0": 4 * N, "sel_hist1": 4 * N, "sel_hist2": 4 * N,
+        "mean_summary": 12 * N, "sel_hist0": 4 * N, "sel_hist1": 4 * N, "sel_hist2": 4 * N,
         "sel_next": 4 * N, "gf_count": 4 * N, "gf_scatter": 12 * N + 12 * NF,
         "db_keys": 24 * NF, "db_gather": 44 * NF, "db_cells": 24 * NF, "db_label": 33 * NF,
         "radix_hist": 8 * NF, "radix_scatter": 24 * NF, "scan_reduce": 4 * NF, "scan_apply": 8 * NF,
@@ -72,7 +72,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--points", type=int, default=100_000_000)
     ap.add_argument("--kind", default="corridor", choices=["corridor", "uniform"])
-    ap.add_argument("--offset", action="store_true", help="add the EPSG:4547-scale global offset")
+    ap.add_argument("--frame", default="offset", choices=["offset", "local"],
+                    help="offset: EPSG:4547-scale coordinates like the reference's data (default); "
+                         "local: corridor starts at the origin")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
@@ -88,7 +90,7 @@ def main():
     torch.cuda.set_device(dev)
     N = int(args.points)
     seed = synth.SEED0 + 2 + rank
-    raw = synth.corridor_torch(N, seed=seed, kind=args.kind, offset=args.offset, device=dev,
+    raw = synth.corridor_torch(N, seed=seed, kind=args.kind, offset=(args.frame == "offset"), device=dev,
                                dtype=torch.float32)
     torch.cuda.synchronize()
 
@@ -171,7 +173,7 @@ def main():
         "config": {"workload": f"{N / 1e6:g} M-pt synthetic {args.kind}, ground filter + chunked "
                                f"DBSCAN(eps={EPS:g}, min_samples={MIN_POINTS}, chunk={CHUNK}) + label "
                                "grouping, 1 tile per GPU (BASELINE configs[2])",
-                   "points_per_gpu": N, "frame": "global-offset" if args.offset else "local",
+                   "points_per_gpu": N, "frame": "global-offset (+437000,+3139000,+80)" if args.frame == "offset" else "local",
                    "filtered_points": NF, "clusters": K, "seed": seed},
         "roofline": roofline,
         "knn_kernel": knn,

@@ -107,18 +107,249 @@ __device__ __forceinline__ long long ms_readlane64(long long v, int lane) {
     return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-// one wave per column
-__global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, int64_t n, int64_t nb,
-                                                const MsHdr* __restrict__ hdr,
-                                                const long long* __restrict__ apos,
-                                                const long long* __restrict__ aneg,
-                                                float* __restrict__ out) {
-    __shared__ float stage[MSB];
+// parity -> increment maps compose associatively: (f then g)(p) = f(p) + g((p + f(p)) & 1)
+__device__ __forceinline__ void ms_scan_pairs(long long& c0, long long& c1) {
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long p0 = __shfl_up(c0, o, 64), p1 = __shfl_up(c1, o, 64);   // earlier segment f
+        if (l >= o) {
+            const long long n0 = p0 + ((p0 & 1) ? c1 : c0);
+            const long long n1 = p1 + (((1 + p1) & 1) ? c1 : c0);
+            c0 = n0; c1 = n1;
+        }
+    }
+}
+
+constexpr int MS_SEG = 16;                       // elements per lane in ms_block_exact
+__device__ __forceinline__ int ms_pad(int i) { return i + (i >> 4); }   // LDS bank spreading
+
+// Adds ONE level-1 block to the running sum exactly, using all 64 lanes: lane l owns the 16
+// consecutive elements [pos+16l, pos+16l+16) and summarises them IN ORDER for the current binade
+// and for both parities of its incoming mantissa (a tie a/u = q+1/2 rounds to the even mantissa,
+// so its increment depends on that parity; after one tie both chains are even and coincide).
+// A parity-pair scan gives every lane its incoming mantissa; lanes whose segment provably stays
+// inside the binade are applied at once, the first segment that does not (an element as large as
+// the sum, a binade or sign change, a non-finite value) is added element by element, and the
+// rest of the block is redone at the new binade.
+__device__ __forceinline__ uint32_t ms_block_exact(const float* __restrict__ xyz, int64_t n, int c,
+                                                   int64_t blk, uint32_t sb, float* stage) {
+    const int l = lane_id();
+    const int64_t p0 = blk * MSB;
+    const int cnt = (int)((n - p0) < MSB ? (n - p0) : MSB);
+    for (int i = l; i < cnt; i += 64) stage[ms_pad(i)] = xyz[3 * (p0 + i) + c];
+    __syncthreads();
+    int pos = 0;
+    while (pos < cnt) {
+        const uint32_t ef = (sb >> 23) & 0xFFu;
+        if (ef == 255u && (sb & 0x7FFFFFu)) break;                 // NaN is absorbing
+        const bool s_norm = ef >= 1u && ef <= 254u;
+        int f = 0;                                                 // first segment to add serially
+        if (s_norm) {
+            const bool s_neg = (sb >> 31) != 0;
+            const int E = (int)ef - 127;
+            const int base = pos + MS_SEG * l;
+            int run0 = 0, run1 = 0, mn0 = 0, mn1 = 0, mx0 = 0, mx1 = 0, par0 = 0, par1 = 1;
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < MS_SEG; ++k) {
+                const int i = base + k;
+                const float a = (i < cnt) ? stage[ms_pad(i)] : 0.0f;
+                const float x = ldexpf(s_neg ? -a : a, 23 - E);     // real increment of the mantissa
+                const float r = rintf(x);
+                bad |= !(fabsf(x) < 8388608.0f);                   // element >= 2^E, inf or NaN
+                int d0 = (int)r, d1 = d0;
+                if (fabsf(x - r) == 0.5f) {                        // tie: pick the even mantissa
+                    const int fl = (int)floorf(x);
+                    d0 = ((par0 + fl) & 1) ? fl + 1 : fl;
+                    d1 = ((par1 + fl) & 1) ? fl + 1 : fl;
+                }
+                run0 += d0; par0 = (par0 + d0) & 1;
+                run1 += d1; par1 = (par1 + d1) & 1;
+                mn0 = run0 < mn0 ? run0 : mn0; mx0 = run0 > mx0 ? run0 : mx0;
+                mn1 = run1 < mn1 ? run1 : mn1; mx1 = run1 > mx1 ? run1 : mx1;
+            }
+            long long c0 = run0, c1 = run1;
+            ms_scan_pairs(c0, c1);
+            const long long m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);
+            const int pc = (int)(m_cur & 1);
+            long long e0 = __shfl_up(c0, 1, 64), e1 = __shfl_up(c1, 1, 64);
+            if (l == 0) { e0 = 0; e1 = 0; }
+            const long long m_in = m_cur + (pc ? e1 : e0);
+            const int pl = (int)(m_in & 1);
+            const long long hi = pl ? mx1 : mx0, lo = pl ? mn1 : mn0;
+            const bool ok = !bad && m_in + hi + 1 < (1ll << 24) && m_in + lo - 1 >= (1ll << 23);
+            const unsigned long long fail = __ballot(base < cnt && !ok);
+            f = fail ? (int)__builtin_ctzll(fail) : 64;
+            if (f > 0) {
+                const long long m1 = m_cur + ms_readlane64(pc ? c1 : c0, f - 1);
+                sb = (sb & 0xFF800000u) | ((uint32_t)m1 & 0x7FFFFFu);
+                pos += MS_SEG * f;
+            }
+            if (!fail) break;                                      // whole remainder applied
+        }
+        // add segment [pos, pos+16) one element at a time (all lanes redundantly, LDS broadcast)
+        float s = __uint_as_float(sb);
+        const int end = pos + MS_SEG < cnt ? pos + MS_SEG : cnt;
+        for (int i = pos; i < end; ++i) s = s + stage[ms_pad(i)];
+        sb = __builtin_amdgcn_readfirstlane(__float_as_uint(s));
+        pos = end;
+    }
+    __syncthreads();
+    return sb;
+}
+
+// ---- level 2: one table row per 64 level-1 blocks (65 536 points), same candidate layout.
+// Order-free bounds are additive, so a parent row is the sum of its children's rows taken at
+// the same absolute binade; a child contributes nothing to candidates more than 24 binades
+// above its own largest element.
+__global__ __launch_bounds__(256) void ms_level2_k(const MsHdr* __restrict__ hdr, const long long* __restrict__ apos,
+                                                   const long long* __restrict__ aneg, int64_t nb, int64_t nb2,
+                                                   MsHdr* __restrict__ hdr2, long long* __restrict__ apos2,
+                                                   long long* __restrict__ aneg2) {
+    const int64_t w = (int64_t)blockIdx.x * 4 + wave_id();
+    if (w >= 3 * nb2) return;
+    const int c = (int)(w / nb2);
+    const int64_t g = w % nb2;
+    const int l = lane_id();
+    const int64_t bb = g * 64 + l;
+    const bool valid = bb < nb;
+    MsHdr h;
+    h.emax = -200; h.tie = 0; h.flags = MS_ALLZERO; h.pad = 0;
+    if (valid) h = hdr[(int64_t)c * nb + bb];
+    const bool zero = (h.flags & MS_ALLZERO) != 0;
+    const int emax2 = wave_reduce_max(zero ? -200 : h.emax);
+    const uint32_t nonfinite = __ballot((h.flags & MS_NONFINITE) != 0) ? MS_NONFINITE : 0u;
+    const bool allzero = __ballot(!zero) == 0;
+    uint32_t tie2 = 0;
+    const int shift = emax2 - h.emax;                      // >= 0 for non-zero children
+    for (int j2 = 0; j2 < MS_CAND; ++j2) {
+        const int j = j2 + shift;
+        long long p = 0, q = 0;
+        bool tie = false;
+        if (valid && !zero && !(h.flags & MS_NONFINITE) && j < MS_CAND) {
+            const int64_t at = ((int64_t)c * nb + bb) * MS_CAND + j;
+            p = apos[at]; q = aneg[at];
+            tie = (h.tie >> j) & 1u;
+        }
+        p = wave_reduce_add(p);
+        q = wave_reduce_add(q);
+        if (__ballot(tie)) tie2 |= 1u << j2;
+        if (l == 0) {
+            const int64_t at2 = ((int64_t)c * nb2 + g) * MS_CAND + j2;
+            apos2[at2] = p; aneg2[at2] = q;
+        }
+    }
+    if (l == 0) {
+        MsHdr o;
+        o.emax = allzero ? 0 : emax2;
+        o.tie = tie2;
+        o.flags = nonfinite | (allzero ? MS_ALLZERO : 0u);
+        o.pad = 0;
+        hdr2[(int64_t)c * nb2 + g] = o;
+    }
+}
+
+// what one lane knows about its level-1 block at the current binade
+struct MsLane {
+    int       cls;      // 0: s cannot change, 1: order-free table bounds, 2: unknown at this E
+    long long net0, net1, lo0, lo1, hi0, hi1;
+    uint32_t  flags;
+    int       j;
+    bool      valid;
+    int64_t   bb;
+};
+
+struct MsTables {
+    const MsHdr* hdr; const long long* apos; const long long* aneg; int64_t nb;      // level 1
+    const MsHdr* hdr2; const long long* apos2; const long long* aneg2; int64_t nb2;  // level 2
+};
+
+__device__ __forceinline__ int ms_classify(const MsHdr& h, bool valid, bool s_inf, bool s_norm, int E, int& j) {
+    j = E - h.emax - 1;
+    if (!valid || (h.flags & MS_ALLZERO)) return 0;
+    if (s_inf) return (h.flags & MS_NONFINITE) ? 2 : 0;
+    if (!s_norm || (h.flags & MS_NONFINITE) || j < 0) return 2;
+    if (j >= MS_CAND) return 0;
+    return ((h.tie >> j) & 1u) ? 2 : 1;
+}
+
+// Adds the level-1 blocks [first, first+count), count <= 64, to the running sum `sb` (bits).
+__device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ xyz, int64_t n, int c,
+                                                     const MsTables& T, int64_t first, int count,
+                                                     uint32_t sb, float* stage, int& n_serial) {
+    const int l = lane_id();
+    int done = 0;                                       // children already added
+    while (done < count) {
+        const uint32_t ef = (sb >> 23) & 0xFFu;
+        if (ef == 255u && (sb & 0x7FFFFFu)) return sb;  // NaN is absorbing
+        const bool s_inf = ef == 255u;
+        const bool s_norm = ef >= 1u && ef <= 254u;
+        const bool s_neg = (sb >> 31) != 0;
+        const int E = (int)ef - 127;
+        MsLane me;
+        me.bb = first + l;
+        me.valid = l >= done && l < count;
+        MsHdr h;
+        h.emax = 0; h.tie = 0; h.flags = MS_ALLZERO; h.pad = 0;
+        if (me.valid) h = T.hdr[(int64_t)c * T.nb + me.bb];
+        me.cls = ms_classify(h, me.valid, s_inf, s_norm, E, me.j);
+        me.flags = h.flags;
+        me.net0 = me.net1 = 0; me.lo0 = me.lo1 = 0; me.hi0 = me.hi1 = 0;
+        if (me.cls == 1) {
+            const int64_t at = ((int64_t)c * T.nb + me.bb) * MS_CAND + me.j;
+            const long long p = T.apos[at], q = T.aneg[at];
+            const long long up = s_neg ? q : p, dn = s_neg ? p : q;
+            me.net0 = me.net1 = up - dn; me.lo0 = me.lo1 = -dn; me.hi0 = me.hi1 = up;
+        }
+        int start = done;                               // first unresolved lane
+        long long m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);   // mantissa entering `start`
+        for (;;) {
+            long long c0 = l >= start ? me.net0 : 0ll, c1 = l >= start ? me.net1 : 0ll;
+            ms_scan_pairs(c0, c1);                      // inclusive: increment through lane l
+            const int pc = (int)(m_cur & 1);
+            const long long incl = pc ? c1 : c0;
+            long long e0 = __shfl_up(c0, 1, 64), e1 = __shfl_up(c1, 1, 64);
+            if (l == 0) { e0 = 0; e1 = 0; }
+            const long long m_in = m_cur + (pc ? e1 : e0);
+            const int pl = (int)(m_in & 1);
+            const long long hi = pl ? me.hi1 : me.hi0, lo = pl ? me.lo1 : me.lo0;
+            const bool ok = me.cls == 0 || (me.cls == 1 && m_in + hi + 1 < (1ll << 24) &&
+                                            m_in + lo - 1 >= (1ll << 23));
+            const unsigned long long fail = __ballot(me.valid && l >= start && !ok);
+            const int f = fail ? (int)__builtin_ctzll(fail) : count;
+            if (f > start && s_norm) {                  // advance over the certified lanes
+                m_cur += ms_readlane64(incl, f - 1);
+                sb = (sb & 0xFF800000u) | ((uint32_t)m_cur & 0x7FFFFFu);
+            }
+            start = f;
+            if (!fail) { done = count; break; }
+            // child f cannot be certified from the table at this E: add it exactly
+            ++n_serial;
+            const uint32_t nsb = ms_block_exact(xyz, n, c, first + f, sb, stage);
+            const bool same = ((nsb ^ sb) & 0xFF800000u) == 0 && s_norm;   // same sign and binade
+            sb = nsb;
+            start = f + 1;
+            done = start;
+            if (same) m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);
+            else break;                                 // re-read the remaining children at the new E
+        }
+    }
+    return sb;
+}
+
+// one wave per column: walks the level-2 rows, descends into the children of a row only when
+// its certificate fails
+__global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, int64_t n, MsTables T,
+                                                float* __restrict__ out, int* __restrict__ stats) {
+    __shared__ float stage[MSB + MSB / 16];
     const int c = blockIdx.x;
     const int l = lane_id();
     uint32_t sb = 0;                                   // bits of the running sum (+0.0)
-    int64_t b = 0;
-    while (b < nb) {
+    int64_t b = 0;                                     // next level-2 row
+    int n_serial = 0, n_batches = 0, n_desc = 0;
+    while (b < T.nb2) {
+        ++n_batches;
         const uint32_t ef = (sb >> 23) & 0xFFu;
         if (ef == 255u && (sb & 0x7FFFFFu)) break;     // NaN is absorbing
         const bool s_inf = ef == 255u;
@@ -126,57 +357,54 @@ __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, i
         const bool s_neg = (sb >> 31) != 0;
         const int E = (int)ef - 127;
         const int64_t bb = b + l;
-        const bool valid = bb < nb;
+        const bool valid = bb < T.nb2;
         MsHdr h;
         h.emax = 0; h.tie = 0; h.flags = MS_ALLZERO; h.pad = 0;
-        if (valid) h = hdr[(int64_t)c * nb + bb];
-        const int j = E - h.emax - 1;
-        // 0 = no change, 1 = table increment, 2 = must be added element by element
-        int cls;
-        if (!valid || (h.flags & MS_ALLZERO)) cls = 0;
-        else if (s_inf) cls = (h.flags & MS_NONFINITE) ? 2 : 0;
-        else if (!s_norm || (h.flags & MS_NONFINITE) || j < 0) cls = 2;
-        else if (j >= MS_CAND) cls = 0;
-        else cls = ((h.tie >> j) & 1u) ? 2 : 1;
-        long long up = 0, dn = 0;
+        if (valid) h = T.hdr2[(int64_t)c * T.nb2 + bb];
+        int j;
+        const int cls = ms_classify(h, valid, s_inf, s_norm, E, j);
+        long long net = 0, lo = 0, hi = 0;
         if (cls == 1) {
-            const int64_t at = ((int64_t)c * nb + bb) * MS_CAND + j;
-            const long long p = apos[at], q = aneg[at];
-            up = s_neg ? q : p;                        // increments of |s|
-            dn = s_neg ? p : q;
+            const int64_t at = ((int64_t)c * T.nb2 + bb) * MS_CAND + j;
+            const long long p = T.apos2[at], q = T.aneg2[at];
+            const long long up = s_neg ? q : p, dn = s_neg ? p : q;
+            net = up - dn; lo = -dn; hi = up;
         }
-        const long long net = up - dn;
-        const long long incl = wave_scan_incl(net);
-        const long long m0 = (long long)((sb & 0x7FFFFFu) | 0x800000u);
-        const long long m_in = m0 + incl - net;
-        const bool ok = cls == 0 || (cls == 1 && m_in + up + 1 < (1ll << 24) && m_in - dn - 1 >= (1ll << 23));
-        const unsigned long long fail = __ballot(valid && !ok);
-        const int f = fail ? (int)__builtin_ctzll(fail) : 64;
-        if (f > 0 && s_norm) {
-            const long long m1 = m0 + ms_readlane64(incl, f - 1);
-            sb = (sb & 0xFF800000u) | ((uint32_t)m1 & 0x7FFFFFu);   // same sign, same binade
+        int start = 0;
+        long long m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);
+        bool reload = false;
+        while (!reload) {
+            const long long incl = wave_scan_incl(l >= start ? net : 0ll);
+            const long long m_in = m_cur + incl - (l >= start ? net : 0ll);
+            const bool ok = cls == 0 || (cls == 1 && m_in + hi + 1 < (1ll << 24) && m_in + lo - 1 >= (1ll << 23));
+            const unsigned long long fail = __ballot(valid && l >= start && !ok);
+            const int f = fail ? (int)__builtin_ctzll(fail) : 64;
+            if (f > start && s_norm) {
+                m_cur += ms_readlane64(incl, f - 1);
+                sb = (sb & 0xFF800000u) | ((uint32_t)m_cur & 0x7FFFFFu);
+            }
+            start = f;
+            if (!fail) break;
+            // descend into the 64 children of row b+f
+            ++n_desc;
+            const int64_t first = (b + f) * 64;
+            const int count = (int)((T.nb - first) < 64 ? (T.nb - first) : 64);
+            const uint32_t nsb = ms_walk_children(xyz, n, c, T, first, count, sb, stage, n_serial);
+            const bool same = ((nsb ^ sb) & 0xFF800000u) == 0 && s_norm;
+            sb = nsb;
+            start = f + 1;
+            if (same) m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);
+            else reload = true;
         }
-        if (!fail) { b += 64; continue; }
-        // exact element-by-element pass over block b+f
-        const int64_t blk = b + f;
-        const int64_t p0 = blk * MSB;
-        const int cnt = (int)((n - p0) < MSB ? (n - p0) : MSB);
-        for (int i = l; i < cnt; i += 64) stage[i] = xyz[3 * (p0 + i) + c];
-        __syncthreads();
-        float s = __uint_as_float(sb);
-        int i = 0;
-        for (; i + 8 <= cnt; i += 8) {
-            const float a0 = stage[i], a1 = stage[i + 1], a2 = stage[i + 2], a3 = stage[i + 3],
-                        a4 = stage[i + 4], a5 = stage[i + 5], a6 = stage[i + 6], a7 = stage[i + 7];
-            s = s + a0; s = s + a1; s = s + a2; s = s + a3;
-            s = s + a4; s = s + a5; s = s + a6; s = s + a7;
-        }
-        for (; i < cnt; ++i) s = s + stage[i];
-        __syncthreads();
-        sb = __builtin_amdgcn_readfirstlane(__float_as_uint(s));
-        b = blk + 1;
+        b += reload ? start : 64;
     }
-    if (l == 0) out[c] = __uint_as_float(sb) / (float)n;    // n == 0 -> 0/0 = NaN like numpy
+    if (l == 0) {
+        out[c] = __uint_as_float(sb) / (float)n;       // n == 0 -> 0/0 = NaN like numpy
+        if (stats) {
+            stats[4 * c + 0] = n_batches; stats[4 * c + 1] = 0;
+            stats[4 * c + 2] = n_serial; stats[4 * c + 3] = n_desc;
+        }
+    }
 }
 
 // single-workgroup reference variant (kept for cross-checking the parallel algorithm)
@@ -209,22 +437,35 @@ __global__ __launch_bounds__(256) void mean_seq_k(const float* __restrict__ xyz,
 }
 
 struct MsWs {
-    MsHdr*     hdr;
-    long long *apos, *aneg;
+    int*       stats;            // [3][4]: level-2 batches, -, exactly added blocks, descents
+    MsHdr     *hdr, *hdr2;
+    long long *apos, *aneg, *apos2, *aneg2;
 };
 static void ms_plan(Arena& a, int64_t n, MsWs& w) {
     const int64_t nb = ceil_div(n > 0 ? n : 1, MSB);
+    w.stats = a.take<int>(16);
     w.hdr = a.take<MsHdr>(3 * nb);
     w.apos = a.take<long long>(3 * nb * MS_CAND);
     w.aneg = a.take<long long>(3 * nb * MS_CAND);
+    const int64_t nb2 = ceil_div(nb, 64);
+    w.hdr2 = a.take<MsHdr>(3 * nb2);
+    w.apos2 = a.take<long long>(3 * nb2 * MS_CAND);
+    w.aneg2 = a.take<long long>(3 * nb2 * MS_CAND);
 }
 static int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, hipStream_t s) {
-    const int64_t nb = ceil_div(n > 0 ? n : 1, MSB);
-    if (n > 0)
+    const int64_t nb = n > 0 ? ceil_div(n, MSB) : 0;
+    const int64_t nb2 = ceil_div(nb, 64);
+    if (n > 0) {
         PCH_LAUNCH("mean_summary", ms_summary_k, dim3((unsigned)ceil_div(nb, MS_WAVES)), dim3(64 * MS_WAVES),
                    0, s, xyz, n, nb, w.hdr, w.apos, w.aneg);
-    PCH_LAUNCH("mean_walk", ms_walk_k, dim3(3), dim3(64), 0, s, xyz, n, n > 0 ? nb : 0,
-               (const MsHdr*)w.hdr, (const long long*)w.apos, (const long long*)w.aneg, out);
+        PCH_LAUNCH("mean_level2", ms_level2_k, dim3((unsigned)ceil_div(3 * nb2, 4)), dim3(256), 0, s,
+                   (const MsHdr*)w.hdr, (const long long*)w.apos, (const long long*)w.aneg, nb, nb2,
+                   w.hdr2, w.apos2, w.aneg2);
+    }
+    MsTables T;
+    T.hdr = w.hdr; T.apos = w.apos; T.aneg = w.aneg; T.nb = nb;
+    T.hdr2 = w.hdr2; T.apos2 = w.apos2; T.aneg2 = w.aneg2; T.nb2 = nb2;
+    PCH_LAUNCH("mean_walk", ms_walk_k, dim3(3), dim3(64), 0, s, xyz, n, T, out, w.stats);
     return PCH_OK;
 }
 
