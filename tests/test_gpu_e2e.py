@@ -1,0 +1,190 @@
+"""End-to-end parity through the drop-in call surface (LAS file in, reference-shaped results
+out) and size-independent properties at BASELINE.json's full sizes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dbscan as odb
+from oracle import ground_filter as ogf
+from oracle import towers as otw
+from oracle import voxel as ovx
+from pointcloudhookup_amd import las, ops, pipeline, synth
+
+pytestmark = pytest.mark.gpu
+
+SCALES = np.array([0.001, 0.001, 0.001])
+OFFSETS = np.array([437000.0, 3139000.0, 0.0])
+
+
+@pytest.fixture(scope="module")
+def config1_las(tmp_path_factory):
+    """BASELINE config 1: 1 M-pt flat ground + 3 Gaussian towers, written as a LAS 1.2 file."""
+    d = tmp_path_factory.mktemp("cfg1")
+    pts = synth.corridor_numpy(1_000_000, seed=synth.SEED0, kind="corridor", offset=True, towers=3)
+    XYZ = np.round((pts - OFFSETS) / SCALES).astype(np.int32)
+    path = str(d / "cloud.las")
+    las.write(path, las.LasHeader(point_format=3, version=(1, 2), scales=SCALES, offsets=OFFSETS), XYZ)
+    xyz = np.stack([ovx.las_scaled(XYZ[:, a], SCALES[a], OFFSETS[a]) for a in range(3)], axis=1)
+    return path, XYZ, xyz, d
+
+
+def test_run_voxel_downsampling_dropin(cuda, config1_las):
+    from pointcloudhookup_amd.ui.import_PC import process_chunk, run_voxel_downsampling
+    path, XYZ, xyz, d = config1_las
+    out = str(d / "output" / "point_2.las")
+    logs, prog = [], []
+    assert run_voxel_downsampling(path, out, voxel_size=0.1, chunk_size=500000,
+                                  progress_callback=prog.append, log_callback=logs.append) is None
+    ridx, rmean, rcnt, roffs = ovx.voxel_down_sample_chunked(xyz, 0.1, 500000)
+    got = las.read(out)
+    ref_XYZ = np.stack([ovx.las_unscale(rmean[:, a], SCALES[a], OFFSETS[a]) for a in range(3)], axis=1)
+    np.testing.assert_array_equal(got.XYZ, ref_XYZ)                 # same voxel set, same order
+    assert got.header.point_format == 3 and tuple(got.header.version) == (1, 2)
+    np.testing.assert_array_equal(got.header.scales, SCALES)
+    assert prog == [50, 100]
+    assert logs[0] == "📂 原始点数: 1000000" and logs[-2] == f"✅ 下采样完成，输出点数: {len(rcnt)}"
+    assert logs[2] == "✅ 已完成第1块：500000 点"
+    m = process_chunk(xyz[:20000], 0.5)
+    np.testing.assert_array_equal(m, ovx.voxel_down_sample(xyz[:20000], 0.5)[1])
+
+
+def test_sampling_cli_twin(cuda, config1_las, capsys):
+    from pointcloudhookup_amd.ui.Sampling import voxel_downsample_open3d
+    path, XYZ, xyz, d = config1_las
+    out = str(d / "out2" / "p.las")
+    voxel_downsample_open3d(path, out, 0.2, 250000)
+    text = capsys.readouterr().out
+    assert "成功生成下采样文件" in text and os.path.exists(out)
+    ref = ovx.voxel_down_sample_chunked(xyz, 0.2, 250000)
+    assert len(las.read(out)) == len(ref[2])
+    voxel_downsample_open3d(str(d / "missing.las"), out, 0.2)       # swallowed like the reference
+    assert "处理过程中发生错误" in capsys.readouterr().out
+
+
+@pytest.mark.parametrize("order", ["unsorted", "trimesh_sorted"])
+def test_extract_towers_dropin_matches_oracle(cuda, oracle_clib, config1_las, monkeypatch, order):
+    from pointcloudhookup_amd.utils import tower_extraction as te
+    path, XYZ, xyz, d = config1_las
+    work = d / f"run_{order}"
+    work.mkdir()
+    monkeypatch.chdir(work)
+    monkeypatch.setattr(te, "OBB_EXTENT_ORDER", order)
+    logs, prog = [], []
+    towers = te.extract_towers(path, progress_callback=prog.append, log_callback=logs.append)
+    ref = otw.extract_towers_arrays(xyz[:, 0], xyz[:, 1], xyz[:, 2], fit="c", extent_order=order)
+    assert len(towers) == len(ref["towers"])
+    if order == "trimesh_sorted":
+        assert len(towers) == 3                                     # BASELINE config 1: 3 towers
+    for t, r in zip(towers, ref["towers"]):
+        assert set(t) == {"center", "rotation", "extent", "height", "width", "north_angle", "points"}
+        np.testing.assert_allclose(t["center"], r["center"], rtol=0, atol=1e-3)   # north_star tolerance
+        np.testing.assert_array_equal(t["center"], r["center"])    # in fact bit identical
+        np.testing.assert_array_equal(t["extent"], r["extent"])
+        np.testing.assert_array_equal(t["rotation"], r["rotation"])
+        assert t["north_angle"] == r["north_angle"]
+        np.testing.assert_array_equal(t["points"].view(np.uint32), r["points"].view(np.uint32))
+        f = work / "output_towers" / f"tower_{r['label']}.las"
+        assert f.exists() and len(las.read(str(f))) == len(r["points"])
+    assert prog[:3] == [5, 10, 20] and prog[-1] == 100 and 75 in prog and prog == sorted(prog)
+    assert f"✅ 点云读取完成，总点数: {len(xyz)}" in logs
+    assert f"✅ 高度过滤完成，保留点数: {len(ref['ground']['filtered'])}" in logs
+    assert f"\n=== 开始杆塔检测（候选簇：{ref['n_candidates']}个） ===" in logs
+    assert logs[-1] == "✅ 杆塔提取完成"
+    if towers:                                                      # openpyxl is absent: logged, not raised
+        assert any(m.startswith("⚠️ 保存Excel失败") or "杆塔信息已保存" in m for m in logs)
+
+
+def test_extract_and_visualize_dropin(cuda, config1_las):
+    from pointcloudhookup_amd.ui.extract import extract_and_visualize_towers
+    path, XYZ, xyz, d = config1_las
+    tower = dict(center=np.array([437050.0, 3139050.0, 100.0]), rotation=np.eye(3),
+                 extent=np.array([20.1, 18.0, 17.4]))
+    cloud, geoms = extract_and_visualize_towers(path, [tower])
+    assert cloud.dtype == np.float64
+    np.testing.assert_array_equal(cloud, xyz)                       # laspy scaled view, bit exact
+    assert len(geoms) == 1 and geoms[0][0].shape == (24, 3) and geoms[0][1] == (1.0, 0.0, 0.0)
+    lo, hi = geoms[0][0].min(0), geoms[0][0].max(0)
+    np.testing.assert_allclose(lo, [437050 - 20.1, 3139050 - 10.05, 100 - 17.4])
+    np.testing.assert_allclose(hi, [437050 + 20.1 * 1.67, 3139050 + 20.1, 100 + 34.8])
+    cloud2, geoms2 = extract_and_visualize_towers(path, [tower], use_kuangxuan_method=False)
+    assert geoms2[0][0].shape == (24, 3)
+
+
+# ------------------------------------------------------------------ BASELINE config 2 (10 M)
+def test_config2_voxel_then_cluster_properties(cuda, oracle_clib):
+    n = 10_000_000
+    xyz = synth.corridor_torch(n, seed=synth.SEED0 + 1, kind="corridor", offset=True, device=cuda)
+    idx, mean, cnt, offs = ops.voxel_downsample(xyz, 0.2, 500000)
+    assert int(cnt.sum()) == n and int(offs[-1]) == idx.shape[0] and offs.shape[0] == 21
+    host = xyz[:500000].cpu().numpy()
+    ridx, rmean, rcnt = ovx.voxel_down_sample(host, 0.2)            # first chunk against the oracle
+    m0 = int(offs[1])
+    np.testing.assert_array_equal(idx[:m0].cpu().numpy(), ridx)
+    np.testing.assert_array_equal(mean[:m0].cpu().numpy(), rmean)
+    np.testing.assert_array_equal(cnt[:m0].cpu().numpy(), rcnt)
+    # idempotence on one chunk: each mean lies in its own voxel
+    i2, m2, c2, _ = ops.voxel_downsample(mean[:m0].contiguous(), 0.2, 0)
+    assert i2.shape[0] <= m0
+    # filter + cluster the voxel output (the GUI's order of operations)
+    raw = ops.cast_f32(mean)
+    cl = pipeline.cluster_points(raw, 8.0, 80, 50000, want_index=True)
+    ref = ogf.ground_filter(raw.cpu().numpy())
+    np.testing.assert_array_equal(cl["ground"]["centroid"].view(np.uint32), ref["centroid"].view(np.uint32))
+    np.testing.assert_array_equal(cl["ground"]["points"].cpu().numpy().view(np.uint32),
+                                  ref["filtered"].view(np.uint32))
+    labels = cl["labels"].cpu().numpy()
+    k = cl["nclusters"]
+    present = np.unique(labels[labels >= 0])
+    np.testing.assert_array_equal(present, np.arange(k))            # ids dense, 0..K-1
+    first = np.array([np.flatnonzero(labels == c)[0] // 50000 for c in range(k)])
+    assert (np.diff(first) >= 0).all()                              # numbered chunk by chunk
+    for ci in (0, len(labels) // 50000 // 2):                       # two chunks against the oracle
+        chunk = ref["filtered"][ci * 50000:(ci + 1) * 50000]
+        want, _ = odb.dbscan_fit_c(chunk, 8.0, 80)
+        g = labels[ci * 50000:(ci + 1) * 50000].astype(np.int64)
+        base = g[g >= 0].min() if (g >= 0).any() else 0
+        np.testing.assert_array_equal(np.where(g >= 0, g - base, -1), want)
+    again = pipeline.cluster_points(raw, 8.0, 80, 50000)
+    assert torch.equal(again["labels"], cl["labels"])               # deterministic
+    offsets = cl["offsets"].cpu().numpy()
+    assert offsets[-1] == (labels >= 0).sum() and (np.diff(offsets) > 0).all()
+
+
+# ------------------------------------------------------------------ BASELINE config 3 (100 M)
+def test_config3_100m_properties(cuda):
+    n = 100_000_000
+    raw = synth.corridor_torch(n, seed=synth.SEED0 + 2, kind="corridor", offset=True, device=cuda,
+                               dtype=torch.float32)
+    cl = pipeline.cluster_points(raw, 8.0, 80, 50000, want_index=True)
+    gf = cl["ground"]
+    c = torch.tensor(gf["centroid"], device=cuda)
+    z = raw[:, 2] - c[2]
+    keep = z > float(gf["threshold"])
+    assert int(keep.sum()) == gf["count"]
+    idx = gf["index"].long()
+    assert bool((idx[1:] > idx[:-1]).all())                         # order preserving compaction
+    assert torch.equal(idx, torch.nonzero(keep).flatten())
+    assert torch.equal(gf["points"], raw[idx] - c)                  # float32 centring, same op
+    # the percentile base sits between the order statistics floor(k) and floor(k)+1, k = (n-1)/4
+    k0 = int(np.floor(np.float32(n - 1) * np.float32(0.25)))
+    base = float(gf["base"])
+    assert int((z < base).sum()) <= k0 + 1 <= int((z <= base).sum()) + 1
+    assert int((z <= base).sum()) >= k0 + 1
+    labels = cl["labels"]
+    k = cl["nclusters"]
+    assert int(labels.max()) == k - 1 and int(labels.min()) >= -1
+    counts = torch.bincount(labels[labels >= 0].long(), minlength=k)
+    offsets = cl["offsets"]
+    assert torch.equal(counts, offsets[1:] - offsets[:-1])          # checksum of the grouping
+    perm = cl["perm"].long()
+    assert torch.equal(labels[perm[: int(offsets[-1])]].long(),
+                       torch.repeat_interleave(torch.arange(k, device=cuda), counts))
+    assert int(counts.min()) >= 1
+    # every cluster lives inside one 50k chunk (reference semantics) and is spatially compact
+    lo = torch.div(perm[offsets[:-1]], 50000, rounding_mode="floor")
+    hi = torch.div(perm[offsets[1:] - 1], 50000, rounding_mode="floor")
+    assert torch.equal(lo, hi)
+    stats = cl["stats"]
+    assert float((stats[:, 3:6] - stats[:, 0:3]).max()) < 200.0

@@ -1,0 +1,267 @@
+"""CPU suite, part 2: host logic of the product package (no compute calls into the HIP
+library - there is no GPU here): LAS I/O, box fit vs the oracle, drop-in call surface, C-ABI
+symbol export, loud failure without a GPU, and the world_size-2 gloo reconciliation."""
+import inspect
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_loads_and_exports_every_declared_symbol():
+    from pointcloudhookup_amd import _lib
+    L = _lib.lib()
+    assert L.pch_version() >= 100
+    header = open(os.path.join(ROOT, "include", "pch_hip.h")).read()
+    declared = set(re.findall(r"\b(pch_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed from include/pch_hip.h"
+    assert declared == set(_lib.exported_symbols())
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (pch_[a-z0-9_]+)", nm))
+    assert declared <= exported, declared - exported
+    # workspace sizing is pure host code and may be called without a device
+    assert L.pch_dbscan_ws_bytes(1000) > 0 and L.pch_ground_filter_ws_bytes(1000) > 0
+    assert L.pch_voxel_downsample_ws_bytes(1000, 100) > 0 and L.pch_segment_by_label_ws_bytes(1000, 3) > 0
+    assert L.pch_mean_seq_f32_ws_bytes(10 ** 8) < 2e8          # summary tables: < 2 B/point
+
+
+def test_product_path_fails_loudly_without_gpu_tensors():
+    import torch
+    from pointcloudhookup_amd import ops
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        ops.ground_filter(torch.zeros((10, 3), dtype=torch.float32))
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        ops.dbscan(torch.zeros((10, 3), dtype=torch.float32))
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        ops.voxel_downsample(torch.zeros((10, 3), dtype=torch.float64), 0.1)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pointcloudhookup_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
+                assert "oracle/" not in txt, f
+
+
+# ------------------------------------------------------------------ LAS
+@pytest.mark.parametrize("fmt,ver", [(0, (1, 2)), (1, (1, 2)), (3, (1, 2)), (2, (1, 3)), (6, (1, 4)), (7, (1, 4))])
+def test_las_roundtrip(tmp_path, fmt, ver):
+    from pointcloudhookup_amd import las
+    rng = np.random.default_rng(fmt)
+    XYZ = rng.integers(-10 ** 8, 10 ** 8, (1234, 3)).astype(np.int32)
+    hdr = las.LasHeader(point_format=fmt, version=ver, scales=np.array([0.001, 0.001, 0.01]),
+                        offsets=np.array([437000.0, 3139000.0, 0.0]))
+    p = str(tmp_path / "t.las")
+    las.write(p, hdr, XYZ)
+    assert os.path.getsize(p) == las.HEADER_SIZE[ver] + 1234 * las.RECORD_LEN[fmt]
+    d = las.read(p)
+    np.testing.assert_array_equal(d.XYZ, XYZ)
+    assert d.header.point_format == fmt and tuple(d.header.version) == ver
+    np.testing.assert_array_equal(d.header.scales, hdr.scales)
+    np.testing.assert_array_equal(d.header.offsets, hdr.offsets)
+    np.testing.assert_array_equal(d.x, XYZ[:, 0] * 0.001 + 437000.0)          # laspy scaled view
+    np.testing.assert_allclose(d.header.maxs, d.XYZ.max(0) * hdr.scales + hdr.offsets)
+
+
+def test_las_errors(tmp_path):
+    from pointcloudhookup_amd import las
+    with pytest.raises(FileNotFoundError):
+        las.read(str(tmp_path / "missing.las"))
+    bad = tmp_path / "bad.las"
+    bad.write_bytes(b"NOPE" + b"\0" * 400)
+    with pytest.raises(ValueError):
+        las.read(str(bad))
+    empty = str(tmp_path / "e.las")
+    las.write(empty, las.LasHeader(), np.zeros((0, 3), np.int32))
+    assert len(las.read(empty)) == 0
+
+
+# ------------------------------------------------------------------ stage D host code vs oracle
+def test_product_obb_equals_oracle_obb():
+    from oracle import obb as o
+    from pointcloudhookup_amd import obb as p
+    rng = np.random.default_rng(0)
+    for t in range(4):
+        P = rng.normal(0, [2.5, 2.5, 9], (6000, 3))
+        P[:, 2] = np.clip(P[:, 2] + 22, 3, 45)
+        R = np.linalg.qr(rng.normal(size=(3, 3)))[0] if t % 2 else np.eye(3)
+        X = (P @ R.T).astype(np.float32)
+        for order in ("unsorted", "trimesh_sorted"):
+            e1, T1 = o.bounding_box_oriented(X, order)
+            e2, T2 = p.bounding_box_oriented(X, order)
+            np.testing.assert_array_equal(e1, e2)
+            np.testing.assert_array_equal(T1, T2)
+    with pytest.raises(ValueError):
+        p.oriented_bounds(X, "sideways")
+
+
+def test_north_angle_matches_oracle():
+    from oracle import towers as ot
+    from pointcloudhookup_amd import pipeline
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        R = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        assert pipeline.north_angle_deg(R) == ot.north_angle_deg(R)
+
+
+def test_extract_boxes_match_reference_golden():
+    from pointcloudhookup_amd.ui import extract as ex
+    g = json.load(open(os.path.join(GOLD, "kuangxuan_boxes.json")))
+    for preset, ref in g["presets"].items():
+        method, params = ex.get_bbox_preset(preset)
+        assert method == "kuangxuan"
+        lo, hi = ex.create_bbox_using_kuangxuan_method(np.array(g["center"]), 20.1, 17.4, **params)
+        np.testing.assert_allclose(lo, ref["min"], atol=5e-3)
+        np.testing.assert_allclose(hi, ref["max"], atol=5e-3)
+        pts, color = ex.create_bbox_lineset_from_bounds(lo, hi)
+        assert pts.shape == (24, 3) and pts.dtype == np.float64 and color == (1.0, 0.0, 0.0)
+        if "lines" in ref:
+            np.testing.assert_array_equal(pts, np.array(ref["lines"]))
+    assert ex.get_bbox_preset("no_such_preset") == ex.get_bbox_preset("kuangxuan_original")
+    boxes = ex.create_enhanced_tower_boxes_kuangxuan(
+        [dict(center=np.array(g["center"]), extent=np.array(g["extent"]), rotation=np.eye(3))])
+    assert [b[0].shape for b in boxes] == [(24, 3), (24, 3), (2, 3)]
+    assert [b[1] for b in boxes] == [(1.0, 0.0, 0.0), (1.0, 1.0, 0.0), (0.0, 1.0, 0.0)]
+    with pytest.raises(FileNotFoundError):
+        ex.extract_and_visualize_towers("/nonexistent/file.las", [])
+
+
+# ------------------------------------------------------------------ drop-in call surface
+REF_SIGS = {
+    # reference file:line of every def the GUI imports
+    ("ui.import_PC", "process_chunk"): ["points_chunk", "voxel_size"],
+    ("ui.import_PC", "run_voxel_downsampling"): ["input_path", "output_path", "voxel_size", "chunk_size",
+                                                 "progress_callback", "log_callback"],
+    ("ui.Sampling", "process_chunk"): ["points_chunk", "las", "voxel_size"],
+    ("ui.Sampling", "voxel_downsample_open3d"): ["input_path", "output_path", "voxel_size", "chunk_size"],
+    ("utils.tower_extraction", "extract_towers"): ["input_las_path", "progress_callback", "log_callback", "eps",
+                                                   "min_points", "aspect_ratio_threshold", "min_height",
+                                                   "max_width", "min_width", "duplicate_threshold"],
+    ("utils.tower_extraction", "_save_tower_las"): ["points", "colors", "header_info", "output_path",
+                                                    "log_callback"],
+    ("utils.tower_extraction", "create_obb_geometries"): ["tower_obbs"],
+    ("ui.extract", "extract_and_visualize_towers"): ["las_path", "tower_obbs", "scale_factors", "line_color",
+                                                     "adaptive_scaling", "use_kuangxuan_method",
+                                                     "kuangxuan_preset"],
+    ("ui.extract", "extract_and_visualize_towers_kuangxuan"): ["las_path", "tower_obbs", "bbox_method",
+                                                               "bbox_params", "line_color"],
+    ("ui.extract", "create_bbox_using_kuangxuan_method"): ["center", "width", "height", "x_left_factor",
+                                                           "x_right_factor", "y_down_factor", "y_up_factor",
+                                                           "z_down_factor", "z_up_factor"],
+}
+REF_DEFAULTS = {
+    ("ui.import_PC", "run_voxel_downsampling"): dict(voxel_size=0.1, chunk_size=1000000),
+    ("ui.Sampling", "voxel_downsample_open3d"): dict(chunk_size=1000000),
+    ("utils.tower_extraction", "extract_towers"): dict(eps=8.0, min_points=80, aspect_ratio_threshold=0.8,
+                                                       min_height=15.0, max_width=50.0, min_width=8,
+                                                       duplicate_threshold=30.0),
+    ("ui.extract", "extract_and_visualize_towers"): dict(use_kuangxuan_method=True,
+                                                         kuangxuan_preset="kuangxuan_original"),
+}
+
+
+@pytest.mark.parametrize("mod,fn", sorted(REF_SIGS))
+def test_dropin_signatures(mod, fn):
+    import importlib
+    m = importlib.import_module(f"pointcloudhookup_amd.{mod}")
+    sig = inspect.signature(getattr(m, fn))
+    assert list(sig.parameters) == REF_SIGS[(mod, fn)]
+    for k, v in REF_DEFAULTS.get((mod, fn), {}).items():
+        assert sig.parameters[k].default == v
+
+
+def test_dropin_twin_module_and_alias():
+    from pointcloudhookup_amd.ui.ui import tower_extraction as twin
+    from pointcloudhookup_amd.utils import tower_extraction as te
+    assert twin.extract_towers is te.extract_towers
+    assert te.extract_towers_optimized.__doc__
+
+
+def test_voxel_dropin_raises_only_for_missing_input(tmp_path):
+    from pointcloudhookup_amd.ui import import_PC
+    with pytest.raises(FileNotFoundError):
+        import_PC.run_voxel_downsampling(str(tmp_path / "nope.las"), str(tmp_path / "out" / "o.las"))
+
+
+def test_extract_towers_never_raises(tmp_path, monkeypatch):
+    """Reference contract (utils/tower_extraction.py:74-76): read failure -> log + []."""
+    from pointcloudhookup_amd.utils import tower_extraction as te
+    monkeypatch.chdir(tmp_path)
+    logs, prog = [], []
+    out = te.extract_towers(str(tmp_path / "missing.las"), progress_callback=prog.append,
+                            log_callback=logs.append)
+    assert out == [] and prog == [5]
+    assert logs[0] == "📂 读取点云文件..." and logs[1].startswith("⚠️ 文件读取失败")
+    assert (tmp_path / "output_towers").is_dir()
+
+
+# ------------------------------------------------------------------ synthetic generators
+def test_synth_generator_shape_and_determinism():
+    from pointcloudhookup_amd import synth
+    a = synth.corridor_numpy(200000, seed=5, towers=3)
+    b = synth.corridor_numpy(200000, seed=5, towers=3)
+    np.testing.assert_array_equal(a, b)
+    assert a.shape == (200000, 3) and a[:, 0].min() >= -15 and a[:, 1].max() < 115
+    L = synth.corridor_length(200000)
+    assert L == pytest.approx(20.0)
+    tower = a[a[:, 2] > 0.45]
+    assert 0.09 < len(tower) / len(a) < 0.11 and tower[:, 2].max() <= 45.0
+    u = synth.corridor_numpy(50000, seed=1, kind="uniform", offset=True)
+    assert u[:, 2].min() >= 80.0 and u[:, 2].max() <= 110.0
+
+
+# ------------------------------------------------------------------ multi-rank reconciliation (gloo)
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from pointcloudhookup_amd import tiles
+rank, world, local = tiles.init_from_env(backend="gloo")
+assert world == 2 and dist.get_backend() == "gloo"
+k = 3 if rank == 0 else 2                       # clusters found on this rank's tile
+table = torch.arange(k * 4, dtype=torch.float32).reshape(k, 4) + 100 * rank
+off, total, glob, owner = tiles.reconcile(k, table)
+assert total == 5 and off == (0 if rank == 0 else 3), (off, total)
+assert owner.tolist() == [0, 0, 0, 1, 1]
+exp = torch.cat([torch.arange(12, dtype=torch.float32).reshape(3, 4),
+                 torch.arange(8, dtype=torch.float32).reshape(2, 4) + 100])
+assert torch.equal(glob, exp)
+# a rank with zero clusters still takes part
+off2, total2, glob2, owner2 = tiles.reconcile(0 if rank == 0 else 4, torch.ones((4, 2)) * rank)
+assert total2 == 4 and off2 == 0 and owner2.tolist() == [1, 1, 1, 1]
+assert tiles.tiles_of_rank(5, rank, world) == ([0, 1, 2] if rank == 0 else [3, 4])
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_reconcile_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
+
+
+def test_dedup_centres_first_wins():
+    from pointcloudhookup_amd import tiles
+    c = np.array([[0, 0, 0], [10, 0, 0], [100, 0, 0], [29.9, 0, 0], [131, 0, 0]], float)
+    assert tiles.dedup_centres(c, 30.0) == [0, 2, 4]          # 1 and 3 duplicate 0; 4 is 31 m from 2
+    assert tiles.dedup_centres(np.zeros((0, 3))) == []
+    assert tiles.reconcile(2, __import__("torch").zeros((2, 8)))[0:2] == (0, 2)   # single process
