@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output directories into the small, tracked summaries in profiles/.
+
+  python profiles/summarize.py <round tag> <stats dir> <pmc_fetch dir> <pmc_write dir> <points>
+
+Writes profiles/<tag>_kernel_stats.csv (per-kernel calls / avg / total from --kernel-trace
+--stats), profiles/<tag>_pmc_traffic.csv (FETCH_SIZE / WRITE_SIZE per launch from the two
+separate --pmc passes) and profiles/traffic.json (what bench.py attaches as `traffic`).
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for
+wide coalesced streams (MI355X_MICROARCH.md, HBM section), so the read side is reported raw
+AND doubled; the doubled figure is the one compared with algorithmic bytes.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag, stats_dir, fetch_dir, write_dir, points = sys.argv[1:6]
+here = os.path.dirname(os.path.abspath(__file__))
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0].replace("pch::", "")
+
+
+rows = list(csv.DictReader(open(glob.glob(os.path.join(stats_dir, "**/*kernel_stats.csv"), recursive=True)[0])))
+ours = [r for r in rows if "pch::" in r["Name"]]
+with open(os.path.join(here, f"{tag}_kernel_stats.csv"), "w") as f:
+    f.write("kernel,calls,avg_us,min_us,max_us,total_ms,percent_of_all_gpu_time\n")
+    for r in sorted(ours, key=lambda r: -float(r["TotalDurationNs"])):
+        f.write(f"{short(r['Name'])},{r['Calls']},{float(r['AverageNs']) / 1e3:.2f},{float(r['MinNs']) / 1e3:.2f},"
+                f"{float(r['MaxNs']) / 1e3:.2f},{float(r['TotalDurationNs']) / 1e6:.3f},{r['Percentage']}\n")
+
+
+def pmc(d, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(glob.glob(os.path.join(d, "**/*counter_collection.csv"), recursive=True)[0])):
+        if r["Counter_Name"] == counter and "pch::" in r["Kernel_Name"]:
+            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return acc
+
+
+fetch, write = pmc(fetch_dir, "FETCH_SIZE"), pmc(write_dir, "WRITE_SIZE")
+names = {"ms_summary_k": "mean_summary", "ms_walk_k": "mean_walk", "ms_level2_k": "mean_level2",
+         "db_core_k": "db_core", "db_union_k": "db_union", "db_border_k": "db_border",
+         "gf_count_k": "gf_count", "gf_scatter_k": "gf_scatter", "sel_hist_k<0>": "sel_hist0",
+         "sel_hist_k<1>": "sel_hist1", "sel_hist_k<2>": "sel_hist2", "rs_scatter_k": "radix_scatter",
+         "rs_hist_k": "radix_hist", "db_gather_k": "db_gather", "db_keys_k": "db_keys",
+         "sg_stats_k": "seg_stats", "db_label_k": "db_label", "db_cellbox_k": "db_cellbox"}
+traffic = {"points": int(points), "unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, KiB->B)",
+           "kernels": {}}
+with open(os.path.join(here, f"{tag}_pmc_traffic.csv"), "w") as f:
+    f.write("kernel,launches,fetch_bytes_raw_per_launch,fetch_bytes_x2_per_launch,write_bytes_per_launch\n")
+    for k in sorted(set(fetch) | set(write), key=lambda k: -sum(fetch.get(k, [0]))):
+        fl, wl = fetch.get(k, []), write.get(k, [])
+        fb = 1024 * sum(fl) / max(len(fl), 1)
+        wb = 1024 * sum(wl) / max(len(wl), 1)
+        f.write(f"{k},{max(len(fl), len(wl))},{fb:.0f},{2 * fb:.0f},{wb:.0f}\n")
+        if k in names:
+            traffic["kernels"][names[k]] = int(2 * fb + wb)
+json.dump(traffic, open(os.path.join(here, "traffic.json"), "w"), indent=1)
+print(open(os.path.join(here, f"{tag}_pmc_traffic.csv")).read())
