@@ -55,7 +55,7 @@ def knn_tile_bytes(points, eps, chunk):
 def algorithmic_bytes(name, N, NF):
     """Compulsory HBM bytes of one launch of kernel `name` ("kernels" table)."""
     table = {
-        "mean_summary": 12 * N, "sel_hist0": 4 * N, "sel_hist1": 4 * N, "sel_hist2": 4 * N,
+        "mean_summary": 16 * N, "sel_hist0": 4 * N, "sel_hist1": 4 * N, "sel_hist2": 4 * N,
         "sel_next": 4 * N, "gf_count": 4 * N, "gf_scatter": 12 * N + 12 * NF,
         "db_keys": 24 * NF, "db_gather": 44 * NF, "db_cells": 24 * NF, "db_label": 33 * NF,
         "radix_hist": 8 * NF, "radix_scatter": 24 * NF, "scan_reduce": 4 * NF, "scan_apply": 8 * NF,
@@ -86,6 +86,8 @@ def main():
     rank, world, local = tiles.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if os.environ.get("PCH_BENCH_SINGLE_DEVICE"):           # rehearsal of the N>1 path on a 1-GPU box
+        local = 0
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     N = int(args.points)
@@ -106,6 +108,8 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     for _ in range(args.warmup):
         cl = step()
     barrier()
@@ -118,7 +122,8 @@ def main():
     prof = ops.get_profile()
     ops.set_profiling(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     NF = int(cl["ground"]["count"])

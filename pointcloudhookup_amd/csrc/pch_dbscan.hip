@@ -291,9 +291,13 @@ __device__ __forceinline__ void uf_union(int* __restrict__ parent, int a, int b)
     }
 }
 
-// one wave per core cell A: for every neighbour core cell B > A not yet in A's component,
-// look for one core pair within eps (lanes over B's points, scalar loop over A's points,
-// leave at the first hit), then unite.
+// one wave per core cell A.  Phase 1 (64 candidate cells at a time, one per lane): neighbour core
+// cells B > A whose core boxes are within eps and whose root differs from A's survive.
+// Phase 2 (wave-wide per survivor): look for one core pair within eps (lanes over B's points,
+// scalar loop over A's points, leave at the first hit), then unite.
+// ROUND 0 only looks at the (up to 3) face-adjacent cells with a larger index: for dense data
+// they connect at the first tile and leave almost nothing but root comparisons for ROUND 1.
+template <int ROUND>
 __global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4* __restrict__ pts,
                                                          const uint32_t* __restrict__ cell_start,
                                                          const uint64_t* __restrict__ cell_key, int m,
@@ -302,28 +306,50 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4*
                                                          const float* __restrict__ cell_box,
                                                          int* __restrict__ parent) {
     __shared__ RowSet rows[DB_WAVES];
+    __shared__ int cand[DB_WAVES][128];
     const int A = blockIdx.x * DB_WAVES + wave_id();
     if (A >= m) return;
     if (cell_ncore[A] == 0) return;
     const int l = lane_id();
     RowSet* rs = &rows[wave_id()];
-    db_rows(g, cell_key, m, cell_key[A], rs);
+    int* cd = cand[wave_id()];
+    const uint64_t keyA = cell_key[A];
+    db_rows(g, cell_key, m, keyA, rs);
+    // flatten the <= 25 runs of <= 5 cells into one candidate list (prefix over the run lengths)
+    int len = 0;
+    if (l < DB_ROWS) { len = rs->cb[l] - rs->ca[l]; len = len < 0 ? 0 : len; }
+    const int incl = wave_scan_incl(len);
+    const int total = __shfl(incl, 63, 64);
+    if (l < DB_ROWS)
+        for (int k = 0; k < len; ++k) cd[incl - len + k] = rs->ca[l] + k;
+    __builtin_amdgcn_wave_barrier();
     const uint32_t as = cell_start[A], ae = cell_start[A + 1];
     const bool a_dense = cell_ncore[A] == (ae - as);
     const float* boxA = cell_box + 6 * (int64_t)A;
-    for (int r = 0; r < DB_ROWS; ++r) {
-        const int cb = rs->cb[r];
-        for (int B = rs->ca[r]; B < cb; ++B) {
-            if (B <= A) continue;                          // every unordered pair once
-            const uint32_t nb = cell_ncore[B];
-            if (nb == 0) continue;
-            const float* boxB = cell_box + 6 * (int64_t)B;
-            if (db_boxbox_d2(boxA, boxB) > g.eps2) continue;
-            int same = 0;
-            if (l == 0) same = uf_find(parent, A) == uf_find(parent, B);
-            if (__shfl(same, 0, 64)) continue;
-            const uint32_t bs = cell_start[B], be = cell_start[B + 1];
-            const bool b_dense = nb == (be - bs);
+    for (int base = 0; base < total; base += 64) {
+        int B = -1;
+        if (base + l < total) B = cd[base + l];
+        bool live = false;
+        if (B > A) {                                       // every unordered pair once
+            bool want = true;
+            if (ROUND == 0) {                              // face neighbours: key differs by one unit
+                const uint64_t d = cell_key[B] - keyA;     // B > A  =>  key(B) > key(A)
+                want = d == 1ull || d == (1ull << g.bx) || d == (1ull << (g.bx + g.by));
+            }
+            if (want && cell_ncore[B] != 0 && !(db_boxbox_d2(boxA, cell_box + 6 * (int64_t)B) > g.eps2))
+                live = uf_find(parent, A) != uf_find(parent, B);
+        }
+        unsigned long long todo = __ballot(live);
+        while (todo) {
+            const int src = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int Bs = __builtin_amdgcn_readlane(B, src);
+            int same = 0;                                  // united meanwhile through another cell?
+            if (l == 0) same = uf_find(parent, A) == uf_find(parent, Bs);
+            if (__builtin_amdgcn_readfirstlane(same)) continue;
+            const uint32_t bs = cell_start[Bs], be = cell_start[Bs + 1];
+            const bool b_dense = cell_ncore[Bs] == (be - bs);
+            const float* boxB = cell_box + 6 * (int64_t)Bs;
             bool connected = false;
             for (uint32_t ia = as; ia < ae && !connected; ++ia) {
                 if (!a_dense && !core_s[ia]) continue;
@@ -336,7 +362,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4*
                     if (__ballot(hit)) { connected = true; break; }
                 }
             }
-            if (connected && l == 0) uf_union(parent, A, B);
+            if (connected && l == 0) uf_union(parent, A, Bs);
         }
     }
 }
@@ -592,7 +618,10 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
                (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, w.core_s, w.cell_ncore);
     PCH_LAUNCH("db_cellbox", db_cellbox_k, dim3(gc), dim3(DB_THREADS), 0, s, (const float4*)w.pts,
                (const uint32_t*)w.cell_start, (const uint8_t*)w.core_s, m, w.cell_box, w.parent, w.comp_min);
-    PCH_LAUNCH("db_union", db_union_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
+    PCH_LAUNCH("db_union0", db_union_k<0>, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
+               (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, (const uint8_t*)w.core_s,
+               (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, w.parent);
+    PCH_LAUNCH("db_union1", db_union_k<1>, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
                (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, (const uint8_t*)w.core_s,
                (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, w.parent);
     PCH_LAUNCH("db_compmin", db_compmin_k, dim3(gc), dim3(DB_THREADS), 0, s, (const float4*)w.pts,

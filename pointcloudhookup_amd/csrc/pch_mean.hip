@@ -1,0 +1,520 @@
+// B1: np.mean(raw, axis=0) on a C-order (n,3) float32 array == SEQUENTIAL float32 running sum
+// per column, then one float32 division by float32(n)  (utils/tower_extraction.py:63).
+//
+// The sequential sum is reproduced bit for bit, in parallel.  While the running sum
+// s = sigma*m*u keeps its sign and stays inside one binade (m in [2^23,2^24), u = ulp(s)),
+//     fl(s + a) = sigma * (m + rne(sigma*a/u)) * u,
+// i.e. the sum is INTEGER addition of per-element increments d_i = rne(a_i/u) that do not depend
+// on m - unless a_i/u has fraction exactly 1/2 (a "tie", resolved towards the even mantissa).
+//
+//   ms_summary_k : one wave per 1024-point block (read ONCE, staged in LDS; the z column is also
+//                  copied out for the percentile passes).  Per column and for the 24 useful
+//                  candidate binades E = emax+1 .. emax+24 (E <= emax: an element as large as
+//                  the sum; E > emax+24: every increment is 0) it stores the signed increment
+//                  sum S_E, one bound A0 = sum ceil|a/ulp(2^(emax+1))| (so that
+//                  sum|d_i| <= (A0 >> j) + 1024) and a tie bit per candidate (an element ties at
+//                  exactly one candidate: the one just above its lowest set bit).
+//   ms_level2_k  : rows for 64 blocks (65 536 points): child rows added at equal absolute binade.
+//   ms_walk_k    : one wave per column walks level-2 rows 64 at a time (prefix scan of the
+//                  increments + per-row certificate that no prefix can leave the binade), opens
+//                  the children of a row that fails, and adds a child that fails exactly with all
+//                  64 lanes (ms_block_exact).
+// Order inside a certified block is irrelevant, hence the result equals the sequential sum.
+#include "pch_mean.h"
+
+namespace pch {
+
+constexpr int MSB       = 1024;    // points per summary block (one wave, 16 per lane)
+constexpr int MS_PER    = 16;
+constexpr int MS_CAND   = 24;
+constexpr int MS_ROW    = MS_CAND + 1;      // level-1 row: S[24], A0
+constexpr int MS_ROW2   = 2 * MS_CAND;      // level-2 row: S[24], A[24]
+constexpr int MS_WAVES  = 4;
+constexpr uint32_t MS_NONFINITE = 1u, MS_ALLZERO = 2u;
+
+struct MsHdr { int emax; uint32_t tie; uint32_t flags; uint32_t pad; };
+
+__global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __restrict__ xyz, int64_t n,
+                                                             int64_t nb, MsHdr* __restrict__ hdr,
+                                                             long long* __restrict__ rows,
+                                                             float* __restrict__ zcol) {
+    __shared__ __attribute__((aligned(16))) float lds[MS_WAVES][MSB * 3];
+    const int64_t blk = (int64_t)blockIdx.x * MS_WAVES + wave_id();
+    if (blk >= nb) return;
+    const int l = lane_id();
+    const int64_t p0 = blk * MSB;
+    const int cnt = (int)((n - p0) < MSB ? (n - p0) : MSB);
+    float* tile = lds[wave_id()];
+    const float* src = xyz + 3 * p0;
+    if (cnt == MSB) {                                    // 12 KiB, 16-byte loads, every byte once
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* t4 = reinterpret_cast<float4*>(tile);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) t4[i * 64 + l] = s4[i * 64 + l];
+    } else {
+        for (int e = l; e < 3 * cnt; e += 64) tile[e] = src[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (zcol) {
+#pragma unroll
+        for (int i = 0; i < MS_PER; ++i) {
+            const int p = i * 64 + l;
+            if (p < cnt) zcol[p0 + p] = tile[3 * p + 2];
+        }
+    }
+    const bool b5 = (l & 32) != 0, b4 = (l & 16) != 0, b3 = (l & 8) != 0;
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        float a[MS_PER];
+#pragma unroll
+        for (int i = 0; i < MS_PER; ++i) {
+            const int p = i * 64 + l;
+            a[i] = (p < cnt) ? tile[3 * p + c] : 0.0f;
+        }
+        uint32_t mx = 0;
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < MS_PER; ++i) {
+            const uint32_t u = __float_as_uint(a[i]) & 0x7FFFFFFFu;
+            mx = u > mx ? u : mx;
+            bad |= (u >= 0x7F800000u);
+        }
+        mx = wave_reduce_max(mx);
+        const bool nonfinite = __ballot(bad) != 0;
+        const int ef = (int)(mx >> 23);
+        const int emax = (ef > 0 ? ef : 1) - 127;
+        // S[j] = sum_i rne(x_i / 2^j).  For j >= 1, fl(x + 1.5*2^(23+j)) rounds x to a multiple of 2^j
+        // (nearest-even) and the integer difference of the two bit patterns is exactly that
+        // multiple, so one float add + one integer add per (element, candidate); |x| < 2^23 keeps
+        // the sum inside the constant's binade.  The 32-bit accumulators wrap; the true sums
+        // (|S| <= 2^27 per lane) are recovered after subtracting the constants.
+        uint32_t acc[MS_CAND];
+#pragma unroll
+        for (int j = 0; j < MS_CAND; ++j) acc[j] = 0;
+        uint32_t tie = 0;
+        int A0 = 0;
+        if (!nonfinite && mx != 0) {
+#pragma unroll
+            for (int i = 0; i < MS_PER; ++i) {
+                const float x = ldexpf(a[i], 22 - emax);       // a / ulp(2^(emax+1)), |x| < 2^23, exact
+                const uint32_t u = __float_as_uint(x) & 0x7FFFFFFFu;
+                A0 += (int)ceilf(fabsf(x));
+                if (u) {                                       // x/2^j ties iff its lowest set bit is 2^(j-1)
+                    const int xe = (int)(u >> 23);
+                    const uint32_t ma = (u & 0x7FFFFFu) | (xe ? 0x800000u : 0u);
+                    const int jt = (xe ? xe : 1) - 150 + (__ffs((int)ma) - 1) + 1;
+                    tie |= (jt >= 0 && jt < MS_CAND) ? (1u << jt) : 0u;
+                }
+                acc[0] += (uint32_t)(int)rintf(x);
+#pragma unroll
+                for (int j = 1; j < MS_CAND; ++j) {
+                    const float magic = (float)(3ull << (22 + j));      // 1.5 * 2^(23+j), exact
+                    acc[j] += __float_as_uint(x + magic);
+                }
+            }
+        }
+        int S[MS_CAND];
+        S[0] = (int)acc[0];
+#pragma unroll
+        for (int j = 1; j < MS_CAND; ++j) {
+            const float magic = (float)(3ull << (22 + j));
+            S[j] = (!nonfinite && mx != 0) ? (int)(acc[j] - (uint32_t)MS_PER * __float_as_uint(magic)) : 0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tie |= __shfl_xor(tie, o, 64);
+        const long long A0w = wave_reduce_add((long long)A0);
+        // transposed reduction: 24 -> 12 -> 6 -> 3 values per lane while summing over the lane
+        // bits 5,4,3 (|partial| <= 2^30 stays in 32 bit), then three 64-bit butterfly steps
+        int v12[12], v6[6], v3[3];
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            v12[i] = (b5 ? S[12 + i] : S[i]) + __shfl_xor(b5 ? S[i] : S[12 + i], 32, 64);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            v6[i] = (b4 ? v12[6 + i] : v12[i]) + __shfl_xor(b4 ? v12[i] : v12[6 + i], 16, 64);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            v3[i] = (b3 ? v6[3 + i] : v6[i]) + __shfl_xor(b3 ? v6[i] : v6[3 + i], 8, 64);
+        long long t[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            t[i] = v3[i];
+            t[i] += __shfl_xor(t[i], 4, 64);
+            t[i] += __shfl_xor(t[i], 2, 64);
+            t[i] += __shfl_xor(t[i], 1, 64);
+        }
+        const int64_t row = (int64_t)c * nb + blk;
+        if ((l & 7) == 0) {
+            const int j0 = (b5 ? 12 : 0) + (b4 ? 6 : 0) + (b3 ? 3 : 0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) rows[row * MS_ROW + j0 + i] = t[i];
+        }
+        if (l == 0) {
+            rows[row * MS_ROW + MS_CAND] = A0w;
+            MsHdr h;
+            h.emax = emax;
+            h.tie = tie;
+            h.flags = (nonfinite ? MS_NONFINITE : 0u) | (mx == 0 ? MS_ALLZERO : 0u);
+            h.pad = 0;
+            hdr[row] = h;
+        }
+    }
+}
+
+__device__ __forceinline__ long long ms_readlane64(long long v, int lane) {
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xFFFFFFFFll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), lane);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// parity -> increment maps compose associatively: (f then g)(p) = f(p) + g((p + f(p)) & 1)
+__device__ __forceinline__ void ms_scan_pairs(long long& c0, long long& c1) {
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long p0 = __shfl_up(c0, o, 64), p1 = __shfl_up(c1, o, 64);   // earlier segment f
+        if (l >= o) {
+            const long long n0 = p0 + ((p0 & 1) ? c1 : c0);
+            const long long n1 = p1 + (((1 + p1) & 1) ? c1 : c0);
+            c0 = n0; c1 = n1;
+        }
+    }
+}
+
+constexpr int MS_SEG = 16;                       // elements per lane in ms_block_exact
+__device__ __forceinline__ int ms_pad(int i) { return i + (i >> 4); }   // LDS bank spreading
+
+// Adds ONE level-1 block to the running sum exactly, using all 64 lanes: lane l owns the 16
+// consecutive elements [pos+16l, pos+16l+16) and summarises them IN ORDER for the current binade
+// and for both parities of its incoming mantissa (a tie a/u = q+1/2 rounds to the even mantissa,
+// so its increment depends on that parity; after one tie both chains are even and coincide).
+// A parity-pair scan gives every lane its incoming mantissa; lanes whose segment provably stays
+// inside the binade are applied at once, the first segment that does not (an element as large as
+// the sum, a binade or sign change, a non-finite value) is added element by element, and the
+// rest of the block is redone at the new binade.
+__device__ __forceinline__ uint32_t ms_block_exact(const float* __restrict__ xyz, int64_t n, int c,
+                                                   int64_t blk, uint32_t sb, float* stage) {
+    const int l = lane_id();
+    const int64_t p0 = blk * MSB;
+    const int cnt = (int)((n - p0) < MSB ? (n - p0) : MSB);
+    for (int i = l; i < cnt; i += 64) stage[ms_pad(i)] = xyz[3 * (p0 + i) + c];
+    __syncthreads();
+    int pos = 0;
+    while (pos < cnt) {
+        const uint32_t ef = (sb >> 23) & 0xFFu;
+        if (ef == 255u && (sb & 0x7FFFFFu)) break;                 // NaN is absorbing
+        const bool s_norm = ef >= 1u && ef <= 254u;
+        int f = 0;                                                 // first segment to add serially
+        if (s_norm) {
+            const bool s_neg = (sb >> 31) != 0;
+            const int E = (int)ef - 127;
+            const int base = pos + MS_SEG * l;
+            int run0 = 0, run1 = 0, mn0 = 0, mn1 = 0, mx0 = 0, mx1 = 0, par0 = 0, par1 = 1;
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < MS_SEG; ++k) {
+                const int i = base + k;
+                const float a = (i < cnt) ? stage[ms_pad(i)] : 0.0f;
+                const float x = ldexpf(s_neg ? -a : a, 23 - E);     // real increment of the mantissa
+                const float r = rintf(x);
+                bad |= !(fabsf(x) < 8388608.0f);                   // element >= 2^E, inf or NaN
+                int d0 = (int)r, d1 = d0;
+                if (fabsf(x - r) == 0.5f) {                        // tie: pick the even mantissa
+                    const int fl = (int)floorf(x);
+                    d0 = ((par0 + fl) & 1) ? fl + 1 : fl;
+                    d1 = ((par1 + fl) & 1) ? fl + 1 : fl;
+                }
+                run0 += d0; par0 = (par0 + d0) & 1;
+                run1 += d1; par1 = (par1 + d1) & 1;
+                mn0 = run0 < mn0 ? run0 : mn0; mx0 = run0 > mx0 ? run0 : mx0;
+                mn1 = run1 < mn1 ? run1 : mn1; mx1 = run1 > mx1 ? run1 : mx1;
+            }
+            long long c0 = run0, c1 = run1;
+            ms_scan_pairs(c0, c1);
+            const long long m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);
+            const int pc = (int)(m_cur & 1);
+            long long e0 = __shfl_up(c0, 1, 64), e1 = __shfl_up(c1, 1, 64);
+            if (l == 0) { e0 = 0; e1 = 0; }
+            const long long m_in = m_cur + (pc ? e1 : e0);
+            const int pl = (int)(m_in & 1);
+            const long long hi = pl ? mx1 : mx0, lo = pl ? mn1 : mn0;
+            const bool ok = !bad && m_in + hi + 1 < (1ll << 24) && m_in + lo - 1 >= (1ll << 23);
+            const unsigned long long fail = __ballot(base < cnt && !ok);
+            f = fail ? (int)__builtin_ctzll(fail) : 64;
+            if (f > 0) {
+                const long long m1 = m_cur + ms_readlane64(pc ? c1 : c0, f - 1);
+                sb = (sb & 0xFF800000u) | ((uint32_t)m1 & 0x7FFFFFu);
+                pos += MS_SEG * f;
+            }
+            if (!fail) break;                                      // whole remainder applied
+        }
+        // add segment [pos, pos+16) one element at a time (all lanes redundantly, LDS broadcast)
+        float s = __uint_as_float(sb);
+        const int end = pos + MS_SEG < cnt ? pos + MS_SEG : cnt;
+        for (int i = pos; i < end; ++i) s = s + stage[ms_pad(i)];
+        sb = __builtin_amdgcn_readfirstlane(__float_as_uint(s));
+        pos = end;
+    }
+    __syncthreads();
+    return sb;
+}
+
+// ---- level 2: one row per 64 level-1 blocks (65 536 points).  Sums and bounds are additive,
+// so a parent row is the sum of its children's rows taken at the same absolute binade; a child
+// contributes nothing to candidates 24 or more binades above its own largest element.
+__global__ __launch_bounds__(256) void ms_level2_k(const MsHdr* __restrict__ hdr,
+                                                   const long long* __restrict__ rows, int64_t nb,
+                                                   int64_t nb2, MsHdr* __restrict__ hdr2,
+                                                   long long* __restrict__ rows2) {
+    const int64_t w = (int64_t)blockIdx.x * 4 + wave_id();
+    if (w >= 3 * nb2) return;
+    const int c = (int)(w / nb2);
+    const int64_t g = w % nb2;
+    const int l = lane_id();
+    const int64_t bb = g * 64 + l;
+    const bool valid = bb < nb;
+    MsHdr h;
+    h.emax = -200; h.tie = 0; h.flags = MS_ALLZERO; h.pad = 0;
+    if (valid) h = hdr[(int64_t)c * nb + bb];
+    const bool zero = (h.flags & MS_ALLZERO) != 0;
+    const int emax2 = wave_reduce_max(zero ? -200 : h.emax);
+    const uint32_t nonfinite = __ballot((h.flags & MS_NONFINITE) != 0) ? MS_NONFINITE : 0u;
+    const bool allzero = __ballot(!zero) == 0;
+    uint32_t tie2 = 0;
+    const int shift = emax2 - h.emax;                      // >= 0 for non-zero children
+    const bool live = valid && !zero && !(h.flags & MS_NONFINITE);
+    const long long* row = rows + ((int64_t)c * nb + (valid ? bb : 0)) * MS_ROW;
+    const long long A0 = live ? row[MS_CAND] : 0;
+    for (int j2 = 0; j2 < MS_CAND; ++j2) {
+        const int j = j2 + shift;
+        long long S = 0, A = 0;
+        bool tie = false;
+        if (live && j < MS_CAND) {
+            S = row[j];
+            A = (A0 >> j) + MSB;                           // >= sum |d_i| of the child at this binade
+            tie = (h.tie >> j) & 1u;
+        }
+        S = wave_reduce_add(S);
+        A = wave_reduce_add(A);
+        if (__ballot(tie)) tie2 |= 1u << j2;
+        if (l == 0) {
+            const int64_t at2 = ((int64_t)c * nb2 + g) * MS_ROW2;
+            rows2[at2 + j2] = S;
+            rows2[at2 + MS_CAND + j2] = A;
+        }
+    }
+    if (l == 0) {
+        MsHdr o;
+        o.emax = allzero ? 0 : emax2;
+        o.tie = tie2;
+        o.flags = nonfinite | (allzero ? MS_ALLZERO : 0u);
+        o.pad = 0;
+        hdr2[(int64_t)c * nb2 + g] = o;
+    }
+}
+
+struct MsTables {
+    const MsHdr* hdr; const long long* rows; int64_t nb;        // level 1
+    const MsHdr* hdr2; const long long* rows2; int64_t nb2;     // level 2
+};
+
+// 0: s cannot change, 1: integer increments with table bounds, 2: unknown at this binade
+__device__ __forceinline__ int ms_classify(const MsHdr& h, bool valid, bool s_inf, bool s_norm, int E, int& j) {
+    j = E - h.emax - 1;
+    if (!valid || (h.flags & MS_ALLZERO)) return 0;
+    if (s_inf) return (h.flags & MS_NONFINITE) ? 2 : 0;
+    if (!s_norm || (h.flags & MS_NONFINITE) || j < 0) return 2;
+    if (j >= MS_CAND) return 0;
+    return ((h.tie >> j) & 1u) ? 2 : 1;
+}
+
+// table entry -> (net increment of |s|, lowest / highest possible prefix) for the sign of s
+__device__ __forceinline__ void ms_bounds(long long S, long long A, bool s_neg, long long& net,
+                                          long long& lo, long long& hi) {
+    const long long up = (A + S + 1) >> 1, dn = (A - S + 1) >> 1;   // sum of positive / negative parts
+    net = s_neg ? -S : S;
+    hi = s_neg ? dn : up;
+    lo = -(s_neg ? up : dn);
+}
+
+// Adds the level-1 blocks [first, first+count), count <= 64, to the running sum `sb` (bits).
+__device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ xyz, int64_t n, int c,
+                                                     const MsTables& T, int64_t first, int count,
+                                                     uint32_t sb, float* stage, int& n_exact) {
+    const int l = lane_id();
+    int done = 0;                                       // children already added
+    while (done < count) {
+        const uint32_t ef = (sb >> 23) & 0xFFu;
+        if (ef == 255u && (sb & 0x7FFFFFu)) return sb;  // NaN is absorbing
+        const bool s_inf = ef == 255u;
+        const bool s_norm = ef >= 1u && ef <= 254u;
+        const bool s_neg = (sb >> 31) != 0;
+        const int E = (int)ef - 127;
+        const int64_t bb = first + l;
+        const bool valid = l >= done && l < count;
+        MsHdr h;
+        h.emax = 0; h.tie = 0; h.flags = MS_ALLZERO; h.pad = 0;
+        if (valid) h = T.hdr[(int64_t)c * T.nb + bb];
+        int j;
+        const int cls = ms_classify(h, valid, s_inf, s_norm, E, j);
+        long long net = 0, lo = 0, hi = 0;
+        if (cls == 1) {
+            const long long* row = T.rows + ((int64_t)c * T.nb + bb) * MS_ROW;
+            ms_bounds(row[j], (row[MS_CAND] >> j) + MSB, s_neg, net, lo, hi);
+        }
+        int start = done;                               // first unresolved lane
+        long long m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);   // mantissa entering `start`
+        for (;;) {
+            const long long incl = wave_scan_incl(l >= start ? net : 0ll);
+            const long long m_in = m_cur + incl - (l >= start ? net : 0ll);
+            const bool ok = cls == 0 || (cls == 1 && m_in + hi + 1 < (1ll << 24) && m_in + lo - 1 >= (1ll << 23));
+            const unsigned long long fail = __ballot(valid && l >= start && !ok);
+            const int f = fail ? (int)__builtin_ctzll(fail) : count;
+            if (f > start && s_norm) {                  // advance over the certified lanes
+                m_cur += ms_readlane64(incl, f - 1);
+                sb = (sb & 0xFF800000u) | ((uint32_t)m_cur & 0x7FFFFFu);
+            }
+            start = f;
+            if (!fail) { done = count; break; }
+            // child f cannot be certified from the table at this binade: add it exactly
+            ++n_exact;
+            const uint32_t nsb = ms_block_exact(xyz, n, c, first + f, sb, stage);
+            const bool same = ((nsb ^ sb) & 0xFF800000u) == 0 && s_norm;   // same sign and binade
+            sb = nsb;
+            start = f + 1;
+            done = start;
+            if (same) m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);
+            else break;                                 // re-read the remaining children at the new binade
+        }
+    }
+    return sb;
+}
+
+// one wave per column: walks the level-2 rows, descends into the children of a row only when
+// its certificate fails
+__global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, int64_t n, MsTables T,
+                                                float* __restrict__ out, int* __restrict__ stats) {
+    __shared__ float stage[MSB + MSB / 16];
+    const int c = blockIdx.x;
+    const int l = lane_id();
+    uint32_t sb = 0;                                   // bits of the running sum (+0.0)
+    int64_t b = 0;                                     // next level-2 row
+    int n_exact = 0, n_batches = 0, n_desc = 0;
+    while (b < T.nb2) {
+        ++n_batches;
+        const uint32_t ef = (sb >> 23) & 0xFFu;
+        if (ef == 255u && (sb & 0x7FFFFFu)) break;     // NaN is absorbing
+        const bool s_inf = ef == 255u;
+        const bool s_norm = ef >= 1u && ef <= 254u;
+        const bool s_neg = (sb >> 31) != 0;
+        const int E = (int)ef - 127;
+        const int64_t bb = b + l;
+        const bool valid = bb < T.nb2;
+        MsHdr h;
+        h.emax = 0; h.tie = 0; h.flags = MS_ALLZERO; h.pad = 0;
+        if (valid) h = T.hdr2[(int64_t)c * T.nb2 + bb];
+        int j;
+        const int cls = ms_classify(h, valid, s_inf, s_norm, E, j);
+        long long net = 0, lo = 0, hi = 0;
+        if (cls == 1) {
+            const long long* row = T.rows2 + ((int64_t)c * T.nb2 + bb) * MS_ROW2;
+            ms_bounds(row[j], row[MS_CAND + j], s_neg, net, lo, hi);
+        }
+        int start = 0;
+        long long m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);
+        bool reload = false;
+        while (!reload) {
+            const long long incl = wave_scan_incl(l >= start ? net : 0ll);
+            const long long m_in = m_cur + incl - (l >= start ? net : 0ll);
+            const bool ok = cls == 0 || (cls == 1 && m_in + hi + 1 < (1ll << 24) && m_in + lo - 1 >= (1ll << 23));
+            const unsigned long long fail = __ballot(valid && l >= start && !ok);
+            const int f = fail ? (int)__builtin_ctzll(fail) : 64;
+            if (f > start && s_norm) {
+                m_cur += ms_readlane64(incl, f - 1);
+                sb = (sb & 0xFF800000u) | ((uint32_t)m_cur & 0x7FFFFFu);
+            }
+            start = f;
+            if (!fail) break;
+            // descend into the 64 children of row b+f
+            ++n_desc;
+            const int64_t first = (b + f) * 64;
+            const int count = (int)((T.nb - first) < 64 ? (T.nb - first) : 64);
+            const uint32_t nsb = ms_walk_children(xyz, n, c, T, first, count, sb, stage, n_exact);
+            const bool same = ((nsb ^ sb) & 0xFF800000u) == 0 && s_norm;
+            sb = nsb;
+            start = f + 1;
+            if (same) m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);
+            else reload = true;
+        }
+        b += reload ? start : 64;
+    }
+    if (l == 0) {
+        out[c] = __uint_as_float(sb) / (float)n;       // n == 0 -> 0/0 = NaN like numpy
+        if (stats) {
+            stats[4 * c + 0] = n_batches; stats[4 * c + 1] = 0;
+            stats[4 * c + 2] = n_exact; stats[4 * c + 3] = n_desc;
+        }
+    }
+}
+
+// single-workgroup reference variant (kept for cross-checking the parallel algorithm)
+constexpr int MS_TILE = 4096;   // points per LDS tile (48 KiB)
+
+__global__ __launch_bounds__(256) void mean_seq_k(const float* __restrict__ xyz, int64_t n,
+                                                  float* __restrict__ out) {
+    __shared__ float tile[MS_TILE * 3];
+    float s = 0.0f;
+    for (int64_t base = 0; base < n; base += MS_TILE) {
+        const int cnt = (int)((n - base) < MS_TILE ? (n - base) : MS_TILE);
+        const float* src = xyz + 3 * base;
+        for (int e = threadIdx.x; e < 3 * cnt; e += 256) tile[e] = src[e];
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const float* col = tile + threadIdx.x;
+            int i = 0;
+            for (; i + 8 <= cnt; i += 8) {
+                const float a0 = col[3 * (i + 0)], a1 = col[3 * (i + 1)], a2 = col[3 * (i + 2)],
+                            a3 = col[3 * (i + 3)], a4 = col[3 * (i + 4)], a5 = col[3 * (i + 5)],
+                            a6 = col[3 * (i + 6)], a7 = col[3 * (i + 7)];
+                s = s + a0; s = s + a1; s = s + a2; s = s + a3;
+                s = s + a4; s = s + a5; s = s + a6; s = s + a7;
+            }
+            for (; i < cnt; ++i) s = s + col[3 * i];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) out[threadIdx.x] = s / (float)n;
+}
+
+void ms_plan(Arena& a, int64_t n, MsWs& w) {
+    const int64_t nb = ceil_div(n > 0 ? n : 1, MSB);
+    const int64_t nb2 = ceil_div(nb, 64);
+    w.stats = a.take<int>(16);
+    w.hdr = a.take<MsHdr>(3 * nb);
+    w.rows = a.take<long long>(3 * nb * MS_ROW);
+    w.hdr2 = a.take<MsHdr>(3 * nb2);
+    w.rows2 = a.take<long long>(3 * nb2 * MS_ROW2);
+}
+
+int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zcol, hipStream_t s) {
+    const int64_t nb = n > 0 ? ceil_div(n, MSB) : 0;
+    const int64_t nb2 = ceil_div(nb, 64);
+    if (n > 0) {
+        PCH_LAUNCH("mean_summary", ms_summary_k, dim3((unsigned)ceil_div(nb, MS_WAVES)), dim3(64 * MS_WAVES),
+                   0, s, xyz, n, nb, w.hdr, w.rows, zcol);
+        PCH_LAUNCH("mean_level2", ms_level2_k, dim3((unsigned)ceil_div(3 * nb2, 4)), dim3(256), 0, s,
+                   (const MsHdr*)w.hdr, (const long long*)w.rows, nb, nb2, w.hdr2, w.rows2);
+    }
+    MsTables T;
+    T.hdr = w.hdr; T.rows = w.rows; T.nb = nb;
+    T.hdr2 = w.hdr2; T.rows2 = w.rows2; T.nb2 = nb2;
+    PCH_LAUNCH("mean_walk", ms_walk_k, dim3(3), dim3(64), 0, s, xyz, n, T, out, w.stats);
+    return PCH_OK;
+}
+
+int mean_seq_serial_launch(const float* xyz, int64_t n, float* out, hipStream_t s) {
+    PCH_LAUNCH("mean_seq_serial", mean_seq_k, dim3(1), dim3(256), 0, s, xyz, n, out);
+    return PCH_OK;
+}
+
+}  // namespace pch

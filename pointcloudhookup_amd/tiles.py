@@ -30,8 +30,8 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:          # RCCL over xGMI on GPUs; PCH_DIST_BACKEND=gloo for CPU rehearsals
+            backend = os.environ.get("PCH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -59,6 +59,9 @@ def reconcile(nclusters, table, group=None):
         return 0, int(nclusters), table[: int(nclusters)], owner
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    out_dev = table.device
+    if dist.get_backend(group) == "gloo" and table.is_cuda:     # gloo rehearsal: exchange on the host
+        table = table.cpu()
     dev = table.device
     cnt = torch.tensor([int(nclusters)], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(cnt) for _ in range(world)]
@@ -74,7 +77,7 @@ def reconcile(nclusters, table, group=None):
     parts = [g[:c] for g, c in zip(gathered, counts)]
     owner = torch.cat([torch.full((c,), r, dtype=torch.int64, device=dev) for r, c in enumerate(counts)])
     offset = int(sum(counts[:rank]))
-    return offset, int(sum(counts)), torch.cat(parts, dim=0), owner
+    return offset, int(sum(counts)), torch.cat(parts, dim=0).to(out_dev), owner.to(out_dev)
 
 
 def dedup_centres(centres, threshold=30.0):
