@@ -61,6 +61,9 @@ def algorithmic_bytes(name, N, NF):
         "radix_hist": 8 * NF, "radix_scatter": 24 * NF, "scan_reduce": 4 * NF, "scan_apply": 8 * NF,
         "seg_keys": 16 * NF, "seg_perm": 8 * NF, "seg_stats": 16 * NF,
         "db_cellbox": 17 * NF, "db_compmin": 17 * NF,
+        # serial certified walk over the level-2 summary rows (3 columns x 400 B per 65 536 points):
+        # a dependency chain on 3 wavefronts, bounded by latency, not by HBM or MFMA
+        "mean_walk": 3 * 400 * (N // 65536 + 1), "mean_level2": 3 * 216 * (N // 1024 + 1),
     }
     return table.get(name)
 
@@ -159,11 +162,22 @@ def main():
     roofline = roof(dom[0], dom[1]) or dict(kernel=dom[0], bound="hbm", achieved=None,
                                             peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None)
     knn = next((roof(r[0], r[1]) for r in kernels if r[0] == "db_core"), None)
+    if knn:                                     # the same kernel priced at its compulsory floor
+        floor = 16 * NF
+        knn["achieved_compulsory_floor"] = round(floor / (knn["avg_ms"] * 1e-3) / 1e9, 1)
+        knn["note"] = ("tile-model bytes (SURVEY 8d); dense cells need no neighbour tiles, so the model "
+                       "over-credits this kernel on tower data - see achieved_compulsory_floor")
+    if roofline.get("kernel") == "mean_walk":
+        roofline["note"] = ("largest kernel by time is the exact-centroid walk: a serial dependency chain on "
+                            "3 wavefronts (latency-bound); see streaming_kernel for the largest HBM-bound kernel")
+    stream = next((roof(r[0], r[1]) for r in kernels
+                   if r[0] not in ("mean_walk", "db_core", "db_union0", "db_union1", "db_border")
+                   and algorithmic_bytes(r[0], N, NF)), None)
     tr_path = os.path.join(ROOT, "profiles", "traffic.json")   # PMC passes, see profiles/README.md
     if os.path.exists(tr_path):
         try:
             tr = json.load(open(tr_path))
-            for r in (roofline, knn):
+            for r in (roofline, knn, stream):
                 if r and tr.get("points") == N and r["kernel"] in tr.get("kernels", {}):
                     r["traffic"] = tr["kernels"][r["kernel"]]
         except Exception:
@@ -181,12 +195,31 @@ def main():
                    "points_per_gpu": N, "frame": "global-offset (+437000,+3139000,+80)" if args.frame == "offset" else "local",
                    "filtered_points": NF, "clusters": K, "seed": seed},
         "roofline": roofline,
+        "streaming_kernel": stream,
         "knn_kernel": knn,
         "gpu_kernel_ms_per_step": round(gpu_ms, 3),
         "kernels": [dict(name=r[0], avg_ms=round(r[1], 4), launches_per_step=r[2] / args.steps,
                          ms_per_step=round(r[3], 4)) for r in kernels[:12]],
         "knn_cell_occupancy": occ,
     }
+
+    # ---- BASELINE config 2 side measurement: the voxel stage on 10 M float64 points (not in `value`)
+    if world == 1:
+        try:
+            nv = 10_000_000
+            xyz64 = synth.corridor_torch(nv, seed=synth.SEED0 + 1, kind="corridor", offset=True, device=dev)
+            ops.voxel_downsample(xyz64, 0.2, 500000)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                vi, vm, vc, vo = ops.voxel_downsample(xyz64, 0.2, 500000)
+            torch.cuda.synchronize()
+            dtv = (time.perf_counter() - t0) / 3
+            out["voxel_stage"] = {"points": nv, "voxel": 0.2, "chunk": 500000, "voxels_out": int(vi.shape[0]),
+                                  "ms": round(dtv * 1e3, 3), "Mpts_per_s": round(nv / dtv / 1e6, 1)}
+            del xyz64, vi, vm, vc, vo
+        except Exception as e:
+            out["voxel_stage"] = {"error": str(e)}
 
     # ---- CPU baseline: the reference's own library calls (numpy + sklearn) on host cores
     if world == 1 and not args.no_cpu_baseline:

@@ -193,15 +193,13 @@ static PctIndex pct_index(int64_t n, double q_percent) {
     return r;
 }
 
-static int select_percentile(const float* base, int64_t n, int64_t stride, const float* sub,
-                             double q_percent, float add1, float add2, SelWs& w, hipStream_t s) {
+// the histogram / pick / next passes (need only the raw values) ...
+static int select_passes(const float* base, int64_t n, int64_t stride, double q_percent, SelWs& w,
+                         hipStream_t s) {
     const PctIndex pi = pct_index(n, q_percent);
-    SelState init;
-    memset(&init, 0, sizeof(init));
-    init.rank = (unsigned long long)pi.k0;
     PCH_HIP_TRY(hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * SEL_BINS, s));
     PCH_HIP_TRY(hipMemsetAsync(w.st, 0, sizeof(SelState), s));
-    PCH_LAUNCH("sel_init", sel_init_k, dim3(1), dim3(1), 0, s, w.st, init.rank);
+    PCH_LAUNCH("sel_init", sel_init_k, dim3(1), dim3(1), 0, s, w.st, (unsigned long long)pi.k0);
     int64_t gb = ceil_div(n, 256 * 16);
     if (gb > 4096) gb = 4096;
     if (gb < 1) gb = 1;
@@ -214,9 +212,34 @@ static int select_percentile(const float* base, int64_t n, int64_t stride, const
     PCH_LAUNCH("sel_pick2", sel_pick_k<2>, dim3(1), blk, 0, s, w.st, w.hist);
     if (!pi.same)
         PCH_LAUNCH("sel_next", sel_next_k, grid, blk, 0, s, base, n, stride, w.st);
+    return PCH_OK;
+}
+// ... and the final interpolation, which is where `sub` (the centroid) enters
+static int select_lerp(int64_t n, const float* sub, double q_percent, float add1, float add2, SelWs& w,
+                       hipStream_t s) {
+    const PctIndex pi = pct_index(n, q_percent);
     PCH_LAUNCH("sel_lerp", sel_lerp_k, dim3(1), dim3(64), 0, s, (const SelState*)w.st, pi.same, pi.gamma,
                sub, add1, add2, w.scal);
     return PCH_OK;
+}
+static int select_percentile(const float* base, int64_t n, int64_t stride, const float* sub,
+                             double q_percent, float add1, float add2, SelWs& w, hipStream_t s) {
+    PCH_TRY(select_passes(base, n, stride, q_percent, w, s));
+    return select_lerp(n, sub, q_percent, add1, add2, w, s);
+}
+
+// per-thread side stream + events: the select passes only need the raw z column, so they run
+// beside the (latency-bound, 3-wave) centroid walk
+struct SideStream { hipStream_t s; hipEvent_t ev_fork, ev_join; bool ok; };
+static SideStream& side_stream() {
+    static thread_local SideStream ss = {nullptr, nullptr, nullptr, false};
+    if (!ss.ok) {
+        if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.ev_fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.ev_join, hipEventDisableTiming) == hipSuccess)
+            ss.ok = true;
+    }
+    return ss;
 }
 
 // =====================================================================================
@@ -475,8 +498,18 @@ extern "C" int pch_ground_filter_f32(const float* raw, int64_t n, double pct, fl
     if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
     const int64_t nb = ceil_div(n, GF_TILE);
 
-    PCH_TRY(mean_seq_launch(raw, n, w.centroid, w.ms, w.zcol, s));
-    PCH_TRY(select_percentile(w.zcol, n, 1, w.centroid + 2, pct, offset, fallback_offset, w.sel, s));
+    SideStream& ss = side_stream();
+    if (ss.ok) {
+        PCH_TRY(mean_seq_launch(raw, n, w.centroid, w.ms, w.zcol, s, ss.ev_fork));
+        PCH_HIP_TRY(hipStreamWaitEvent(ss.s, ss.ev_fork, 0));
+        PCH_TRY(select_passes(w.zcol, n, 1, pct, w.sel, ss.s));
+        PCH_HIP_TRY(hipEventRecord(ss.ev_join, ss.s));
+        PCH_HIP_TRY(hipStreamWaitEvent(s, ss.ev_join, 0));
+    } else {
+        PCH_TRY(mean_seq_launch(raw, n, w.centroid, w.ms, w.zcol, s));
+        PCH_TRY(select_passes(w.zcol, n, 1, pct, w.sel, s));
+    }
+    PCH_TRY(select_lerp(n, w.centroid + 2, pct, offset, fallback_offset, w.sel, s));
     PCH_HIP_TRY(hipMemsetAsync(w.st, 0, sizeof(GfState), s));
     PCH_LAUNCH("gf_count", gf_count_k, dim3((unsigned)nb), dim3(GF_THREADS), 0, s, (const float*)w.zcol, n,
                (const float*)w.centroid, (const float*)w.sel.scal, w.cnt_a, w.cnt_b);

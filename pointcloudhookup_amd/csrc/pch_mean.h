@@ -13,7 +13,9 @@ struct MsWs {
 void ms_plan(Arena& a, int64_t n, MsWs& w);
 // centroid[3] = np.mean(xyz, axis=0) (float32).  zcol (optional, n floats) receives a copy of
 // the z column, written by the same pass that reads the tile.
-int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zcol, hipStream_t s);
+// ev_zcol (optional) is recorded on `s` right after the pass that writes zcol.
+int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zcol, hipStream_t s,
+                    hipEvent_t ev_zcol = nullptr);
 int mean_seq_serial_launch(const float* xyz, int64_t n, float* out, hipStream_t s);
 
 }  // namespace pch

@@ -496,12 +496,14 @@ void ms_plan(Arena& a, int64_t n, MsWs& w) {
     w.rows2 = a.take<long long>(3 * nb2 * MS_ROW2);
 }
 
-int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zcol, hipStream_t s) {
+int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zcol, hipStream_t s,
+                    hipEvent_t ev_zcol) {
     const int64_t nb = n > 0 ? ceil_div(n, MSB) : 0;
     const int64_t nb2 = ceil_div(nb, 64);
     if (n > 0) {
         PCH_LAUNCH("mean_summary", ms_summary_k, dim3((unsigned)ceil_div(nb, MS_WAVES)), dim3(64 * MS_WAVES),
                    0, s, xyz, n, nb, w.hdr, w.rows, zcol);
+        if (ev_zcol) PCH_HIP_TRY(hipEventRecord(ev_zcol, s));
         PCH_LAUNCH("mean_level2", ms_level2_k, dim3((unsigned)ceil_div(3 * nb2, 4)), dim3(256), 0, s,
                    (const MsHdr*)w.hdr, (const long long*)w.rows, nb, nb2, w.hdr2, w.rows2);
     }
