@@ -21,11 +21,13 @@ constexpr int DB_THREADS = 256;
 constexpr int DB_WAVES   = DB_THREADS / 64;
 constexpr int DB_ROWS    = 25;
 constexpr int INT_BIG    = 0x7fffffff;
+constexpr int DB_FEW_QUERIES = 24;   // below: candidate-parallel radius count, else query-parallel tiles
 
 struct DbGrid {
     float   ox, oy, oz;          // grid origin (lower corner of the bounding box)
     double  cell;                // cell side s
     double  eps2;                // eps*eps (sklearn _dist_to_rdist)
+    float   eps2_lo, eps2_hi;    // float32 pre-filter: d32 <= lo is surely inside, d32 >= hi surely outside
     int     bx, by, bz;          // key bits per axis
     int     mx, my, mz;          // largest valid cell coordinate per axis
     int64_t chunk_size;
@@ -52,6 +54,20 @@ __device__ __forceinline__ bool db_within(const float4& q, const float4& p, doub
     d += dy * dy;
     d += dz * dz;
     return d <= eps2;
+}
+
+// Same predicate, cheaper: the float32 value d32 of the squared distance carries a relative error
+// below 5*2^-24 (one rounding per difference, product and accumulation, all terms non-negative),
+// so with a 2^-20 guard band d32 <= eps2*(1-2^-20) implies d64 <= eps2 and d32 >= eps2*(1+2^-20)
+// implies d64 > eps2; only pairs inside the band are evaluated exactly.
+__device__ __forceinline__ bool db_within2(const float4& q, const float4& p, const DbGrid& g) {
+    const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+    float d = dx * dx;
+    d = __builtin_fmaf(dy, dy, d);
+    d = __builtin_fmaf(dz, dz, d);
+    if (d <= g.eps2_lo) return true;
+    if (d >= g.eps2_hi) return false;
+    return db_within(q, p, g.eps2);
 }
 
 // squared distance from a point to an axis-aligned box, same operation order as db_within;
@@ -164,8 +180,18 @@ __device__ __forceinline__ int db_upper(const uint64_t* __restrict__ a, int m, u
 }
 
 __device__ __forceinline__ void db_rows(const DbGrid& g, const uint64_t* __restrict__ cell_key, int m,
-                                        uint64_t key, RowSet* __restrict__ rs) {
+                                        uint64_t key, RowSet* __restrict__ rs,
+                                        const int2* __restrict__ rowtab = nullptr, int cell = 0) {
     const int l = lane_id();
+    if (rowtab) {                                          // computed once by db_rowtab_k
+        if (l < DB_ROWS) {
+            const int2 v = rowtab[(int64_t)cell * DB_ROWS + l];
+            rs->ca[l] = v.x;
+            rs->cb[l] = v.y;
+        }
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
     if (l < DB_ROWS) {
         const uint64_t cx = key & ((1ull << g.bx) - 1);
         const uint64_t cy = (key >> g.bx) & ((1ull << g.by) - 1);
@@ -186,15 +212,43 @@ __device__ __forceinline__ void db_rows(const DbGrid& g, const uint64_t* __restr
     __builtin_amdgcn_wave_barrier();
 }
 
+// neighbour-row table: [cell][25] cell-index ranges, shared by the core / union / border kernels
+__global__ __launch_bounds__(DB_THREADS) void db_rowtab_k(DbGrid g, const uint64_t* __restrict__ cell_key,
+                                                          int m, int2* __restrict__ rowtab) {
+    const int c = (blockIdx.x * DB_WAVES + wave_id()) * 2 + (lane_id() >> 5);   // two cells per wave
+    const int l = lane_id() & 31;
+    if (c >= m || l >= DB_ROWS) return;
+    const uint64_t key = cell_key[c];
+    const uint64_t cx = key & ((1ull << g.bx) - 1);
+    const uint64_t cy = (key >> g.bx) & ((1ull << g.by) - 1);
+    const uint64_t cz = (key >> (g.bx + g.by)) & ((1ull << g.bz) - 1);
+    const int sh = g.bx + g.by + g.bz;
+    const uint64_t chunk = sh < 64 ? (key >> sh) : 0;
+    const int ny = (int)cy + DB_ROW_DY[l], nz = (int)cz + DB_ROW_DZ[l];
+    int2 v;
+    v.x = 0; v.y = 0;
+    if (ny >= 0 && ny <= g.my && nz >= 0 && nz <= g.mz) {
+        const int xlo = (int)cx - 2 < 0 ? 0 : (int)cx - 2;
+        const int xhi = (int)cx + 2 > g.mx ? g.mx : (int)cx + 2;
+        v.x = db_lower(cell_key, m, db_pack(g, chunk, (uint64_t)nz, (uint64_t)ny, (uint64_t)xlo));
+        v.y = db_upper(cell_key, m, db_pack(g, chunk, (uint64_t)nz, (uint64_t)ny, (uint64_t)xhi));
+    }
+    rowtab[(int64_t)c * DB_ROWS + l] = v;
+}
+
 // ---- core points ---------------------------------------------------------------------
-// one wave per cell.  Dense cell: all core.  Sparse cell: per query point, lanes sweep the
-// candidate runs and count with ballot/popcount, leaving as soon as min_samples is reached.
+// one wave per cell.  Dense cell: all core.  Sparse cell: n-body tile loop - every lane owns one
+// query point of the cell, candidate tiles (64 points of the sorted neighbour runs) are staged
+// once in LDS and broadcast to all queries; the wave leaves as soon as every query has reached
+// min_samples (checked per tile).  Each candidate is loaded once per cell, not once per query.
 __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* __restrict__ pts,
                                                         const uint32_t* __restrict__ cell_start,
                                                         const uint64_t* __restrict__ cell_key, int m,
+                                                        const int2* __restrict__ rowtab,
                                                         uint8_t* __restrict__ core_s,
                                                         uint32_t* __restrict__ cell_ncore) {
     __shared__ RowSet rows[DB_WAVES];
+    __shared__ __attribute__((aligned(16))) float4 tiles[DB_WAVES][64];
     const int c = blockIdx.x * DB_WAVES + wave_id();
     if (c >= m) return;
     const int l = lane_id();
@@ -206,7 +260,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
         return;
     }
     RowSet* rs = &rows[wave_id()];
-    db_rows(g, cell_key, m, cell_key[c], rs);
+    db_rows(g, cell_key, m, cell_key[c], rs, rowtab, c);
     // candidate total: if even all candidates together are too few, nobody is core
     long long tot = 0;
     if (l < DB_ROWS) tot = (long long)cell_start[rs->cb[l]] - (long long)cell_start[rs->ca[l]];
@@ -217,21 +271,81 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
         return;
     }
     uint32_t ncore = 0;
-    for (uint32_t q = s; q < e; ++q) {
-        const float4 qp = pts[q];
-        int count = 0;
-        for (int r = 0; r < DB_ROWS && count < g.min_samples; ++r) {
-            const uint32_t pa = cell_start[rs->ca[r]], pb = cell_start[rs->cb[r]];
-            for (uint32_t j0 = pa; j0 < pb && count < g.min_samples; j0 += 64) {
-                const uint32_t j = j0 + l;
-                bool hit = false;
-                if (j < pb) hit = db_within(qp, pts[j], g.eps2);
-                count += (int)__popcll(__ballot(hit));
+    if (cnt < DB_FEW_QUERIES) {
+        // a handful of queries (cluster fringe): lanes sweep the candidates of one query at a
+        // time and leave at min_samples - usually within the first tile of a dense neighbour
+        for (uint32_t q = s; q < e; ++q) {
+            const float4 qp = pts[q];
+            int count = 0;
+            for (int r = 0; r < DB_ROWS && count < g.min_samples; ++r) {
+                const uint32_t pa = cell_start[rs->ca[r]], pb = cell_start[rs->cb[r]];
+                for (uint32_t j0 = pa; j0 < pb && count < g.min_samples; j0 += 64) {
+                    const uint32_t j = j0 + l;
+                    bool hit = false;
+                    if (j < pb) hit = db_within2(qp, pts[j], g);
+                    count += (int)__popcll(__ballot(hit));
+                }
             }
+            const bool is_core = count >= g.min_samples;
+            if (l == 0) core_s[q] = is_core ? 1 : 0;
+            ncore += is_core;
         }
-        const bool is_core = count >= g.min_samples;
-        if (l == 0) core_s[q] = is_core ? 1 : 0;
-        ncore += is_core;
+        if (l == 0) cell_ncore[c] = ncore;
+        return;
+    }
+    float4* tile = tiles[wave_id()];
+    for (uint32_t q0 = s; q0 < e; q0 += 64) {              // 64 query points per round
+        const bool valid = q0 + l < e;
+        float4 Q;
+        Q.x = Q.y = Q.z = 3.0e37f; Q.w = 0.0f;             // idle lanes sit far away (finite)
+        if (valid) Q = pts[q0 + l];
+        int count = 0;
+        unsigned long long active = __ballot(valid);        // queries still below min_samples
+        int r = 0;
+        uint32_t j0 = cell_start[rs->ca[0]];
+        // phase 1: all queries against one staged candidate tile at a time, while enough of
+        // them are still counting to keep the lanes busy
+        while (r < DB_ROWS && __popcll(active) >= DB_FEW_QUERIES / 2) {
+            const uint32_t pb = cell_start[rs->cb[r]];
+            if (j0 >= pb) { ++r; if (r < DB_ROWS) j0 = cell_start[rs->ca[r]]; continue; }
+            const int nj = (int)((pb - j0) < 64u ? (pb - j0) : 64u);
+            float4 P;
+            P.x = P.y = P.z = 3.0e38f; P.w = 0.0f;         // padding: squared distance overflows to +inf
+            if (l < nj) P = pts[j0 + l];
+            __builtin_amdgcn_wave_barrier();
+            tile[l] = P;
+            __builtin_amdgcn_wave_barrier();
+            const int n8 = (nj + 7) & ~7;
+            for (int k = 0; k < n8; k += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) count += db_within2(Q, tile[k + u], g) ? 1 : 0;
+            }
+            j0 += 64;
+            active = __ballot(valid && count < g.min_samples);
+        }
+        // phase 2: the few stragglers one by one, lanes over the remaining candidates
+        while (active) {
+            const int ql = (int)__builtin_ctzll(active);
+            active &= active - 1;
+            float4 qp;
+            qp.x = __shfl(Q.x, ql, 64); qp.y = __shfl(Q.y, ql, 64); qp.z = __shfl(Q.z, ql, 64); qp.w = 0.0f;
+            int cq = __shfl(count, ql, 64);
+            int rr = r;
+            uint32_t jj = j0;
+            while (rr < DB_ROWS && cq < g.min_samples) {
+                const uint32_t pb = cell_start[rs->cb[rr]];
+                if (jj >= pb) { ++rr; if (rr < DB_ROWS) jj = cell_start[rs->ca[rr]]; continue; }
+                const uint32_t j = jj + l;
+                bool hit = false;
+                if (j < pb) hit = db_within2(qp, pts[j], g);
+                cq += (int)__popcll(__ballot(hit));
+                jj += 64;
+            }
+            if (l == ql) count = cq;
+        }
+        const bool is_core = valid && count >= g.min_samples;
+        if (valid) core_s[q0 + l] = is_core ? 1 : 0;
+        ncore += (uint32_t)__popcll(__ballot(is_core));
     }
     if (l == 0) cell_ncore[c] = ncore;
 }
@@ -301,6 +415,7 @@ template <int ROUND>
 __global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4* __restrict__ pts,
                                                          const uint32_t* __restrict__ cell_start,
                                                          const uint64_t* __restrict__ cell_key, int m,
+                                                         const int2* __restrict__ rowtab,
                                                          const uint8_t* __restrict__ core_s,
                                                          const uint32_t* __restrict__ cell_ncore,
                                                          const float* __restrict__ cell_box,
@@ -314,7 +429,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4*
     RowSet* rs = &rows[wave_id()];
     int* cd = cand[wave_id()];
     const uint64_t keyA = cell_key[A];
-    db_rows(g, cell_key, m, keyA, rs);
+    db_rows(g, cell_key, m, keyA, rs, rowtab, A);
     // flatten the <= 25 runs of <= 5 cells into one candidate list (prefix over the run lengths)
     int len = 0;
     if (l < DB_ROWS) { len = rs->cb[l] - rs->ca[l]; len = len < 0 ? 0 : len; }
@@ -336,8 +451,12 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4*
                 const uint64_t d = cell_key[B] - keyA;     // B > A  =>  key(B) > key(A)
                 want = d == 1ull || d == (1ull << g.bx) || d == (1ull << (g.bx + g.by));
             }
-            if (want && cell_ncore[B] != 0 && !(db_boxbox_d2(boxA, cell_box + 6 * (int64_t)B) > g.eps2))
-                live = uf_find(parent, A) != uf_find(parent, B);
+            if (want && cell_ncore[B] != 0 && !(db_boxbox_d2(boxA, cell_box + 6 * (int64_t)B) > g.eps2)) {
+                // plain (possibly stale) loads first: equal parents were in one set at some time,
+                // and sets only ever merge
+                live = parent[A] != parent[B];
+                if (live) live = uf_find(parent, A) != uf_find(parent, B);
+            }
         }
         unsigned long long todo = __ballot(live);
         while (todo) {
@@ -358,13 +477,21 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4*
                 for (uint32_t j0 = bs; j0 < be; j0 += 64) {
                     const uint32_t j = j0 + l;
                     bool hit = false;
-                    if (j < be && (b_dense || core_s[j])) hit = db_within(pa, pts[j], g.eps2);
+                    if (j < be && (b_dense || core_s[j])) hit = db_within2(pa, pts[j], g);
                     if (__ballot(hit)) { connected = true; break; }
                 }
             }
             if (connected && l == 0) uf_union(parent, A, Bs);
         }
     }
+}
+
+// path compression between the union rounds: afterwards parent[c] is the root of c
+__global__ __launch_bounds__(DB_THREADS) void db_flatten_k(int* __restrict__ parent, int m) {
+    const int c = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (c >= m) return;
+    const int r = uf_find(parent, c);
+    if (r != c) atomicMin(&parent[c], r);
 }
 
 // root of every core cell + smallest original row among the component's core points
@@ -426,6 +553,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_label_k(const float4* __restric
 __global__ __launch_bounds__(DB_THREADS) void db_border_k(DbGrid g, const float4* __restrict__ pts,
                                                           const uint32_t* __restrict__ cell_start,
                                                           const uint64_t* __restrict__ cell_key, int m,
+                                                          const int2* __restrict__ rowtab,
                                                           const uint8_t* __restrict__ core_s,
                                                           const uint32_t* __restrict__ cell_ncore,
                                                           const float* __restrict__ cell_box,
@@ -438,7 +566,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_border_k(DbGrid g, const float4
     if (cell_ncore[A] == (ae - as)) return;                // no border candidates here
     const int l = lane_id();
     RowSet* rs = &rows[wave_id()];
-    db_rows(g, cell_key, m, cell_key[A], rs);
+    db_rows(g, cell_key, m, cell_key[A], rs, rowtab, A);
     // quick reject: no core cell anywhere around
     int any = 0;
     if (l < DB_ROWS)
@@ -461,7 +589,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_border_k(DbGrid g, const float4
                 for (uint32_t j0 = bs; j0 < be; j0 += 64) {
                     const uint32_t j = j0 + l;
                     bool hit = false;
-                    if (j < be && (b_dense || core_s[j])) hit = db_within(qp, pts[j], g.eps2);
+                    if (j < be && (b_dense || core_s[j])) hit = db_within2(qp, pts[j], g);
                     if (__ballot(hit)) { best = lab; break; }
                 }
             }
@@ -482,6 +610,8 @@ struct DbWs {
     uint8_t*  core_s;
     float*    cell_box;
     int      *parent, *root, *comp_min, *cell_label;
+    int2*     rowtab;
+    int64_t   rowtab_cells;
 };
 
 static void db_plan(Arena& a, int64_t n, DbWs& w) {
@@ -506,6 +636,10 @@ static void db_plan(Arena& a, int64_t n, DbWs& w) {
     w.flag = a.take<uint32_t>(nn + 8);
     w.radix_ws = a.take<uint32_t>(radix_ws_u32(nn));
     w.scan_ws = a.take<uint32_t>(scan_ws_u32(nn));
+    // neighbour-row table (200 B per cell) for up to max(n/4, 64Ki) cells; beyond that the rows are
+    // searched on the fly
+    w.rowtab_cells = nn / 4 > 65536 ? nn / 4 : (nn < 65536 ? nn : 65536);
+    w.rowtab = a.take<int2>((size_t)w.rowtab_cells * DB_ROWS);
 }
 
 // host mirror of f32_unordered
@@ -574,6 +708,9 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
     g.ox = box[0]; g.oy = box[1]; g.oz = box[2];
     g.cell = eps / 1.7320508075688772 * (1.0 - 1.0 / 65536.0);
     g.eps2 = eps * eps;
+    g.eps2_lo = nextafterf((float)(g.eps2 * (1.0 - 1.0 / 1048576.0)), -INFINITY);
+    g.eps2_hi = nextafterf((float)(g.eps2 * (1.0 + 1.0 / 1048576.0)), INFINITY);
+    if (!(g.eps2_hi < 3.0e38f)) { g.eps2_lo = -1.0f; g.eps2_hi = NAN; }    // absurd eps: exact path only
     g.chunk_size = chunk_size;
     g.min_samples = min_samples;
     double ext[3];
@@ -614,16 +751,26 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
     PCH_LAUNCH("db_cells", db_cells_k, dim3(gn), dim3(DB_THREADS), 0, s, ks, (const uint32_t*)w.head, n,
                w.cid, w.cell_start, w.cell_key);
     const unsigned gc = (unsigned)ceil_div(m, DB_WAVES);
+    const int2* rowtab = nullptr;
+    if (m <= w.rowtab_cells) {
+        PCH_LAUNCH("db_rowtab", db_rowtab_k, dim3((unsigned)ceil_div(m, 2 * DB_WAVES)), dim3(DB_THREADS), 0, s,
+                   g, (const uint64_t*)w.cell_key, m, w.rowtab);
+        rowtab = w.rowtab;
+    }
     PCH_LAUNCH("db_core", db_core_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
-               (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, w.core_s, w.cell_ncore);
+               (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, w.core_s, w.cell_ncore);
     PCH_LAUNCH("db_cellbox", db_cellbox_k, dim3(gc), dim3(DB_THREADS), 0, s, (const float4*)w.pts,
                (const uint32_t*)w.cell_start, (const uint8_t*)w.core_s, m, w.cell_box, w.parent, w.comp_min);
     PCH_LAUNCH("db_union0", db_union_k<0>, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
-               (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, (const uint8_t*)w.core_s,
+               (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, (const uint8_t*)w.core_s,
                (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, w.parent);
+    PCH_LAUNCH("db_flatten", db_flatten_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
+               w.parent, m);
     PCH_LAUNCH("db_union1", db_union_k<1>, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
-               (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, (const uint8_t*)w.core_s,
+               (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, (const uint8_t*)w.core_s,
                (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, w.parent);
+    PCH_LAUNCH("db_flatten", db_flatten_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
+               w.parent, m);
     PCH_LAUNCH("db_compmin", db_compmin_k, dim3(gc), dim3(DB_THREADS), 0, s, (const float4*)w.pts,
                (const uint32_t*)w.cell_start, (const uint8_t*)w.core_s, (const uint32_t*)w.cell_ncore, m,
                w.parent, w.root, w.comp_min);
@@ -636,7 +783,7 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
                (const int*)w.comp_min, (const uint32_t*)w.flag, n, (const uint32_t*)w.cell_start,
                w.cell_label, labels, core);
     PCH_LAUNCH("db_border", db_border_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
-               (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, (const uint8_t*)w.core_s,
+               (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, (const uint8_t*)w.core_s,
                (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, (const int*)w.cell_label, labels);
     PCH_LAUNCH("db_finish", db_finish_k, dim3(1), dim3(64), 0, s, (const uint32_t*)(w.meta + 8), out_nclusters);
     return PCH_OK;
