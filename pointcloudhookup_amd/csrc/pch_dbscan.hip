@@ -430,13 +430,32 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4*
     int* cd = cand[wave_id()];
     const uint64_t keyA = cell_key[A];
     db_rows(g, cell_key, m, keyA, rs, rowtab, A);
-    // flatten the <= 25 runs of <= 5 cells into one candidate list (prefix over the run lengths)
-    int len = 0;
-    if (l < DB_ROWS) { len = rs->cb[l] - rs->ca[l]; len = len < 0 ? 0 : len; }
-    const int incl = wave_scan_incl(len);
-    const int total = __shfl(incl, 63, 64);
-    if (l < DB_ROWS)
-        for (int k = 0; k < len; ++k) cd[incl - len + k] = rs->ca[l] + k;
+    int total;
+    if (ROUND == 0) {
+        // the three face neighbours with a larger key: +x is the next cell in sorted order, +y / +z
+        // sit in the runs (dy,dz) = (1,0) / (0,1) (rows 1 and 3 of DB_ROW_DY/DZ)
+        if (l < 3) {
+            int B = -1;
+            if (l == 0) {
+                if (A + 1 < m && cell_key[A + 1] == keyA + 1ull) B = A + 1;
+            } else {
+                const int r = l == 1 ? 1 : 3;
+                const uint64_t want = keyA + (l == 1 ? (1ull << g.bx) : (1ull << (g.bx + g.by)));
+                for (int k = rs->ca[r]; k < rs->cb[r]; ++k)
+                    if (cell_key[k] == want) B = k;
+            }
+            cd[l] = B;
+        }
+        total = 3;
+    } else {
+        // flatten the <= 25 runs of <= 5 cells into one candidate list (prefix over the run lengths)
+        int len = 0;
+        if (l < DB_ROWS) { len = rs->cb[l] - rs->ca[l]; len = len < 0 ? 0 : len; }
+        const int incl = wave_scan_incl(len);
+        total = __shfl(incl, 63, 64);
+        if (l < DB_ROWS)
+            for (int k = 0; k < len; ++k) cd[incl - len + k] = rs->ca[l] + k;
+    }
     __builtin_amdgcn_wave_barrier();
     const uint32_t as = cell_start[A], ae = cell_start[A + 1];
     const bool a_dense = cell_ncore[A] == (ae - as);
@@ -446,12 +465,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4*
         if (base + l < total) B = cd[base + l];
         bool live = false;
         if (B > A) {                                       // every unordered pair once
-            bool want = true;
-            if (ROUND == 0) {                              // face neighbours: key differs by one unit
-                const uint64_t d = cell_key[B] - keyA;     // B > A  =>  key(B) > key(A)
-                want = d == 1ull || d == (1ull << g.bx) || d == (1ull << (g.bx + g.by));
-            }
-            if (want && cell_ncore[B] != 0 && !(db_boxbox_d2(boxA, cell_box + 6 * (int64_t)B) > g.eps2)) {
+            if (cell_ncore[B] != 0 && !(db_boxbox_d2(boxA, cell_box + 6 * (int64_t)B) > g.eps2)) {
                 // plain (possibly stale) loads first: equal parents were in one set at some time,
                 // and sets only ever merge
                 live = parent[A] != parent[B];
