@@ -31,6 +31,7 @@ struct DbGrid {
     int     bx, by, bz;          // key bits per axis
     int     mx, my, mz;          // largest valid cell coordinate per axis
     int64_t chunk_size;
+    int64_t trash_chunk;         // chunk id given to the points of chunks that hold NaN/inf
     int     min_samples;
 };
 
@@ -91,15 +92,31 @@ __device__ __forceinline__ double db_boxbox_d2(const float* __restrict__ a, cons
     return d;
 }
 
-// ---- bounding box of the input (only when the caller did not provide one) ------------
+// ---- chunks that contain NaN/inf: sklearn raises for such a chunk and the reference leaves it
+// at -1 (utils/tower_extraction.py:118-119); its points are parked in an extra "trash" chunk
+__global__ __launch_bounds__(DB_THREADS) void db_chunkbad_k(const float* __restrict__ xyz, int64_t n,
+                                                            int64_t chunk_size, uint32_t* __restrict__ bad) {
+    for (int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * DB_THREADS) {
+        const uint32_t a = __float_as_uint(xyz[3 * i + 0]) & 0x7FFFFFFFu;
+        const uint32_t b = __float_as_uint(xyz[3 * i + 1]) & 0x7FFFFFFFu;
+        const uint32_t c = __float_as_uint(xyz[3 * i + 2]) & 0x7FFFFFFFu;
+        if (a >= 0x7F800000u || b >= 0x7F800000u || c >= 0x7F800000u) atomicOr(&bad[i / chunk_size], 1u);
+    }
+}
+
+// ---- bounding box of the finite input points (only when the caller did not provide one) ------
 __global__ __launch_bounds__(DB_THREADS) void db_aabb_in_k(const float* __restrict__ xyz, int64_t n,
                                                            uint32_t* __restrict__ mm) {
     uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
     for (int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * DB_THREADS) {
+        const float x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        if (!(fabsf(x) < INFINITY && fabsf(y) < INFINITY && fabsf(z) < INFINITY)) continue;
+        const float v[3] = {x, y, z};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const uint32_t k = f32_ordered(xyz[3 * i + a]);
+            const uint32_t k = f32_ordered(v[a]);
             lo[a] = k < lo[a] ? k : lo[a];
             hi[a] = k > hi[a] ? k : hi[a];
         }
@@ -108,17 +125,26 @@ __global__ __launch_bounds__(DB_THREADS) void db_aabb_in_k(const float* __restri
     for (int a = 0; a < 3; ++a) {
         lo[a] = wave_reduce_min(lo[a]);
         hi[a] = wave_reduce_max(hi[a]);
-        if (lane_id() == 0) { atomicMin(&mm[a], lo[a]); atomicMax(&mm[3 + a], hi[a]); }
+        if (lane_id() == 0) {
+            if (lo[a] != 0xFFFFFFFFu) atomicMin(&mm[a], lo[a]);
+            if (hi[a] != 0u) atomicMax(&mm[3 + a], hi[a]);
+        }
     }
 }
 
 // ---- cell keys -----------------------------------------------------------------------
 __global__ __launch_bounds__(DB_THREADS) void db_keys_k(const float* __restrict__ xyz, int64_t n,
-                                                        DbGrid g, uint64_t* __restrict__ keys,
+                                                        DbGrid g, const uint32_t* __restrict__ bad,
+                                                        uint64_t* __restrict__ keys,
                                                         uint32_t* __restrict__ vals,
                                                         uint32_t* __restrict__ status) {
     const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
     if (i >= n) return;
+    vals[i] = (uint32_t)i;
+    if (bad[i / g.chunk_size]) {                           // the whole chunk stays noise
+        keys[i] = db_pack(g, (uint64_t)g.trash_chunk, 0, 0, 0);
+        return;
+    }
     const float x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     const double fx = floor(((double)x - (double)g.ox) / g.cell);
     const double fy = floor(((double)y - (double)g.oy) / g.cell);
@@ -128,7 +154,6 @@ __global__ __launch_bounds__(DB_THREADS) void db_keys_k(const float* __restrict_
     if (!ok) atomicOr(status, 1u);
     const uint64_t cx = ok ? (uint64_t)fx : 0, cy = ok ? (uint64_t)fy : 0, cz = ok ? (uint64_t)fz : 0;
     keys[i] = db_pack(g, (uint64_t)(i / g.chunk_size), cz, cy, cx);
-    vals[i] = (uint32_t)i;
 }
 
 // sorted order: gather coordinates (+ original row in .w) and flag cell heads
@@ -254,6 +279,14 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
     const int l = lane_id();
     const uint32_t s = cell_start[c], e = cell_start[c + 1];
     const int cnt = (int)(e - s);
+    {
+        const int sh = g.bx + g.by + g.bz;
+        if (sh < 64 && (int64_t)(cell_key[c] >> sh) == g.trash_chunk) {   // points of NaN/inf chunks
+            for (uint32_t i = s + l; i < e; i += 64) core_s[i] = 0;
+            if (l == 0) cell_ncore[c] = 0;
+            return;
+        }
+    }
     if (cnt >= g.min_samples) {
         for (uint32_t i = s + l; i < e; i += 64) core_s[i] = 1;
         if (l == 0) cell_ncore[c] = (uint32_t)cnt;
@@ -626,11 +659,13 @@ struct DbWs {
     int      *parent, *root, *comp_min, *cell_label;
     int2*     rowtab;
     int64_t   rowtab_cells;
+    uint32_t* chunk_bad;
 };
 
 static void db_plan(Arena& a, int64_t n, DbWs& w) {
     const int64_t nn = n > 0 ? n : 1;
     w.meta = a.take<uint32_t>(16);
+    w.chunk_bad = a.take<uint32_t>(nn + 8);              // one word per chunk (chunk_size >= 1)
     w.k0 = a.take<uint64_t>(nn);
     w.k1 = a.take<uint64_t>(nn);
     w.v0 = a.take<uint32_t>(nn);
@@ -698,23 +733,32 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
     if (chunk_size <= 0 || chunk_size > n) chunk_size = n;
     const int64_t nchunks = ceil_div(n, chunk_size);
 
+    int64_t gstride = ceil_div(n, DB_THREADS * 8);
+    if (gstride > 2048) gstride = 2048;
+    PCH_HIP_TRY(hipMemsetAsync(w.chunk_bad, 0, sizeof(uint32_t) * (size_t)(nchunks + 1), s));
+    PCH_LAUNCH("db_chunkbad", db_chunkbad_k, dim3((unsigned)gstride), dim3(DB_THREADS), 0, s, xyz, n,
+               chunk_size, w.chunk_bad);
     float box[6];
     if (aabb_host) {
         memcpy(box, aabb_host, sizeof(box));
     } else {
         PCH_HIP_TRY(hipMemsetAsync(w.meta, 0xFF, 3 * sizeof(uint32_t), s));
         PCH_HIP_TRY(hipMemsetAsync(w.meta + 3, 0, 3 * sizeof(uint32_t), s));
-        int64_t gb = ceil_div(n, DB_THREADS * 8);
-        if (gb > 2048) gb = 2048;
-        PCH_LAUNCH("db_aabb_in", db_aabb_in_k, dim3((unsigned)gb), dim3(DB_THREADS), 0, s, xyz, n, w.meta);
+        PCH_LAUNCH("db_aabb_in", db_aabb_in_k, dim3((unsigned)gstride), dim3(DB_THREADS), 0, s, xyz, n, w.meta);
         uint32_t mm[6];
         PCH_HIP_TRY(hipMemcpyAsync(mm, w.meta, sizeof(mm), hipMemcpyDeviceToHost, s));
         PCH_HIP_TRY(hipStreamSynchronize(s));
+        if (mm[0] == 0xFFFFFFFFu) {                        // not a single finite point: every chunk fails
+            PCH_HIP_TRY(hipMemsetAsync(labels, 0xFF, sizeof(int32_t) * (size_t)n, s));
+            if (core) PCH_HIP_TRY(hipMemsetAsync(core, 0, (size_t)n, s));
+            PCH_HIP_TRY(hipMemsetAsync(out_nclusters, 0, sizeof(int32_t), s));
+            return PCH_OK;
+        }
         for (int k = 0; k < 6; ++k) box[k] = host_unordered(mm[k]);
     }
     for (int k = 0; k < 6; ++k) {
         if (!(box[k] == box[k]) || box[k] > 3.0e38f || box[k] < -3.0e38f) {
-            set_error("non-finite coordinates (sklearn: ValueError: Input contains NaN/inf)");
+            set_error("bounding box is not finite");
             return PCH_ERR_ARG;
         }
     }
@@ -726,6 +770,7 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
     g.eps2_hi = nextafterf((float)(g.eps2 * (1.0 + 1.0 / 1048576.0)), INFINITY);
     if (!(g.eps2_hi < 3.0e38f)) { g.eps2_lo = -1.0f; g.eps2_hi = NAN; }    // absurd eps: exact path only
     g.chunk_size = chunk_size;
+    g.trash_chunk = nchunks;
     g.min_samples = min_samples;
     double ext[3];
     int mc[3];
@@ -738,7 +783,7 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
     g.bx = bits_for((uint64_t)g.mx + 1);
     g.by = bits_for((uint64_t)g.my + 1);
     g.bz = bits_for((uint64_t)g.mz + 1);
-    const int nbits = g.bx + g.by + g.bz + bits_for((uint64_t)nchunks);
+    const int nbits = g.bx + g.by + g.bz + bits_for((uint64_t)nchunks + 1);
     if (nbits > 64) {
         set_error("cell key needs %d bits (> 64): extent/eps too large for this chunking", nbits);
         return PCH_ERR_RANGE;
@@ -746,7 +791,8 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
 
     const unsigned gn = (unsigned)ceil_div(n, DB_THREADS);
     PCH_HIP_TRY(hipMemsetAsync(w.meta + 6, 0, 4 * sizeof(uint32_t), s));
-    PCH_LAUNCH("db_keys", db_keys_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, n, g, w.k0, w.v0, w.meta + 6);
+    PCH_LAUNCH("db_keys", db_keys_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, n, g,
+               (const uint32_t*)w.chunk_bad, w.k0, w.v0, w.meta + 6);
     PCH_TRY(radix_sort_pairs(w.k0, w.v0, w.k1, w.v1, n, nbits, w.radix_ws, s));
     const bool in1 = radix_sort_result_buffer(nbits) == 1;
     const uint64_t* ks = in1 ? w.k1 : w.k0;
@@ -757,8 +803,7 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
     PCH_HIP_TRY(hipMemcpyAsync(st_m, w.meta + 6, sizeof(st_m), hipMemcpyDeviceToHost, s));
     PCH_HIP_TRY(hipStreamSynchronize(s));
     if (st_m[0] != 0) {
-        set_error("coordinates outside the supplied bounding box or non-finite "
-                  "(sklearn: ValueError: Input contains NaN/inf)");
+        set_error("finite coordinates outside the supplied bounding box");
         return PCH_ERR_ARG;
     }
     const int m = (int)st_m[1];

@@ -369,9 +369,12 @@ __global__ __launch_bounds__(256) void gf_aabb_k(const float* __restrict__ pts, 
     // every thread always sees the same axis
     const int64_t stride = (int64_t)gridDim.x * 256 * 3;
     for (int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 3; e0 < total; e0 += stride) {
+        const float x = pts[e0], y = pts[e0 + 1], z = pts[e0 + 2];
+        if (!(fabsf(x) < INFINITY && fabsf(y) < INFINITY && fabsf(z) < INFINITY)) continue;   // NaN/inf rows
+        const float v[3] = {x, y, z};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const uint32_t k = f32_ordered(pts[e0 + a]);
+            const uint32_t k = f32_ordered(v[a]);
             lo[a] = k < lo[a] ? k : lo[a];
             hi[a] = k > hi[a] ? k : hi[a];
         }

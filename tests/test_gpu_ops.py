@@ -256,6 +256,32 @@ def test_dbscan_edge_cases(cuda):
     assert labels.numel() == 0 and k == 0
 
 
+def test_dbscan_nonfinite_chunk_stays_noise(cuda, oracle_clib):
+    """sklearn raises ValueError for a chunk holding NaN/inf; the reference catches it and leaves
+    that chunk at -1 while the other chunks (and the label counter) carry on
+    (utils/tower_extraction.py:118-119)."""
+    rng = np.random.default_rng(4)
+    X = np.vstack([rng.normal([c, 50, 22], [2.5, 2.5, 9], (2000, 3)) for c in (100, 400, 700)]).astype(np.float32)
+    X = X[rng.permutation(len(X))]
+    bad = X.copy()
+    bad[2500, 0] = np.nan                      # chunk 1 of 3 (chunk size 2000)
+    bad[2600, 1] = np.inf
+    want = np.full(len(X), -1, np.int64)
+    cur = 0
+    for s0 in (0, 4000):                       # chunks 0 and 2 are clustered, chunk 1 raises
+        lab, _ = odb.dbscan_fit_c(X[s0:s0 + 2000], 8.0, 80)
+        lab = lab.copy()
+        lab[lab >= 0] += cur
+        want[s0:s0 + 2000] = lab
+        cur = lab.max() + 1 if (lab >= 0).any() else cur
+    labels, core, k = ops.dbscan(_dev(bad, cuda), 8.0, 80, 2000, want_core=True)
+    np.testing.assert_array_equal(labels.cpu().numpy(), want)
+    assert k == cur and int(core.cpu().numpy()[2000:4000].sum()) == 0
+    allbad = np.full((100, 3), np.nan, np.float32)
+    labels, _, k = ops.dbscan(_dev(allbad, cuda), 8.0, 5, 0)
+    assert k == 0 and (labels.cpu().numpy() == -1).all()
+
+
 def test_dbscan_border_tie_takes_smallest_cluster(cuda):
     # two dense lines, one border point exactly between them within eps of both
     a = np.column_stack([np.linspace(0, 1, 30), np.zeros(30), np.zeros(30)])
