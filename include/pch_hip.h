@@ -65,6 +65,13 @@ int pch_voxel_downsample_f64(const double* xyz, int64_t n, double voxel_size,
                              int64_t* out_chunk_offsets, int64_t* out_m,
                              void* ws, size_t ws_bytes, void* stream);
 
+/* LAS point records -> X,Y,Z: gathers the three little-endian int32 at the start of every
+ * `record_len`-byte record (LAS 1.0-1.4 point formats 0-10 all start with X,Y,Z).
+ * Replaces: laspy's record parsing behind las.X/.Y/.Z (ui/import_PC.py:28,
+ *           utils/tower_extraction.py:60-61).  records: raw bytes [n*record_len] on the device. */
+int pch_las_records_xyz_i32(const uint8_t* records, int64_t n, int32_t record_len,
+                            int32_t* out_XYZ, void* stream);
+
 /* laspy scaled view, stage A0: out = (double)X * scale + offset (no FMA).
  * Replaces: the chunk.x/.y/.z reads at ui/import_PC.py:47-48 and las.x/.y/.z at
  *           utils/tower_extraction.py:62.  XYZ [n,3] int32 (LAS record ints, AoS). */
@@ -128,6 +135,8 @@ int pch_ground_filter_f32(const float* raw, int64_t n, double pct, float offset,
  *            reference's all_labels
  * core       [n] uint8 (may be NULL): 1 for core samples
  * out_nclusters [1] int32
+ * A chunk that contains NaN/inf is left at -1 and does not advance the label counter (sklearn
+ * raises ValueError for it and the reference catches that, utils/tower_extraction.py:118-119).
  * Exact rule implemented (equals sklearn's sweep): neighbours are
  * sum_j((double)x_j-(double)y_j)^2 <= eps*eps; core = >= min_samples neighbours incl.
  * self; clusters = components of the core graph numbered by smallest core index;

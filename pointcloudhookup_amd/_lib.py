@@ -31,6 +31,7 @@ _SIGS = {
     "pch_device_count": (C.c_int, []),
     "pch_voxel_downsample_ws_bytes": (_sz, [_i64, _i64]),
     "pch_voxel_downsample_f64": (C.c_int, [_vp, _i64, _f64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pch_las_records_xyz_i32": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "pch_las_scale_i32_f64": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "pch_las_unscale_f64_i32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "pch_cast_f64_f32": (C.c_int, [_vp, _i64, _vp, _vp]),

@@ -276,6 +276,20 @@ __global__ void las_scale_k(const int32_t* __restrict__ X, int64_t count, D3 sc,
     const int a = (int)(e % 3);
     out[e] = (double)X[e] * sc.v[a] + of.v[a];          // separate mul, add (-ffp-contract=off)
 }
+// one thread per coordinate: three 4-byte loads at the head of each record (records need not be
+// 4-byte aligned: formats 2, 7, 8 ... have odd lengths), assembled from bytes when misaligned
+__global__ void las_records_k(const uint8_t* __restrict__ rec, int64_t count, int record_len,
+                              int32_t* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    const int64_t i = e / 3;
+    const int a = (int)(e - 3 * i);
+    const uint8_t* p = rec + i * record_len + 4 * a;
+    uint32_t v;
+    if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) v = *reinterpret_cast<const uint32_t*>(p);
+    else v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    out[e] = (int32_t)v;
+}
 __global__ void las_unscale_k(const double* __restrict__ v, int64_t count, D3 sc, D3 of,
                               int32_t* __restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -288,6 +302,18 @@ __global__ void cast_f64_f32_k(const double* __restrict__ in, int64_t count, flo
     if (e < count) out[e] = (float)in[e];
 }
 }  // namespace pch
+
+extern "C" int pch_las_records_xyz_i32(const uint8_t* records, int64_t n, int32_t record_len,
+                                       int32_t* out_XYZ, void* stream) {
+    prof_begin_call();
+    PCH_REQUIRE(n >= 0 && record_len >= 12, "bad argument");
+    if (n == 0) return PCH_OK;
+    PCH_REQUIRE(records && out_XYZ, "null buffer");
+    const int64_t count = 3 * n;
+    PCH_LAUNCH("las_records", las_records_k, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0,
+               (hipStream_t)stream, records, count, (int)record_len, out_XYZ);
+    return PCH_OK;
+}
 
 extern "C" int pch_las_scale_i32_f64(const int32_t* XYZ, int64_t n, const double* scale3_host,
                                      const double* offset3_host, double* out_xyz, void* stream) {

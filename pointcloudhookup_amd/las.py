@@ -101,6 +101,29 @@ def read(path):
     return LasData(hdr, XYZ)
 
 
+def read_device(path, device):
+    """Header + X,Y,Z decoded ON THE DEVICE: the raw record bytes are copied to the GPU as they
+    lie in the file (memory mapped, no host-side strided gather) and ``ops.las_records_xyz`` picks
+    the three int32 of every record.  Returns (LasHeader, int32 [n,3] device tensor)."""
+    import torch
+    from . import ops
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    hdr = read_header(path)
+    n, rl = hdr.point_count, hdr.record_length
+    if n == 0:
+        return hdr, torch.zeros((0, 3), dtype=torch.int32, device=device)
+    mm = np.memmap(path, dtype=np.uint8, mode="r", offset=hdr.offset_to_points, shape=(n * rl,))
+    out = torch.empty((n, 3), dtype=torch.int32, device=device)
+    step = max(1, (256 << 20) // rl)                      # ~256 MiB of records per hop
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        rec = torch.from_numpy(np.array(mm[s * rl:e * rl])).to(device)        # one host copy out of the page cache
+        out[s:e] = ops.las_records_xyz(rec, e - s, rl)
+    del mm
+    return hdr, out
+
+
 def write(path, header, XYZ):
     """Writes a LAS file with ``header``'s point_format / version / scales / offsets and the
     given int32 X,Y,Z; every other record field is zero."""

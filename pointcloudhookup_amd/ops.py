@@ -92,6 +92,18 @@ def voxel_downsample(xyz, voxel_size, chunk_size=0):
     return idx[:m], mean[:m], count[:m], offs
 
 
+def las_records_xyz(records_u8, n, record_len):
+    """Raw LAS point records (uint8 device tensor) -> int32 [n,3] X,Y,Z."""
+    L = _lib.lib()
+    rec = _need_cuda(records_u8, torch.uint8, "records")
+    if rec.numel() < int(n) * int(record_len):
+        raise ValueError("record buffer shorter than n * record_len")
+    out = torch.empty((int(n), 3), dtype=torch.int32, device=rec.device)
+    with torch.cuda.device(rec.device):
+        _lib.check(L.pch_las_records_xyz_i32(_ptr(rec), int(n), int(record_len), _ptr(out), _stream()))
+    return out
+
+
 def las_scale(XYZ_i32, scales, offsets):
     """laspy scaled view: int32 [n,3] -> float64 [n,3] (X*scale+offset)."""
     import ctypes as C

@@ -74,12 +74,11 @@ def _read_cloud(las_path):
     import torch
     from .. import las as _las
     from .. import ops
-    data = _las.read(las_path)
-    if len(data) == 0:
-        return np.zeros((0, 3))
     dev = os.environ.get("PCH_DEVICE", "cuda:0")
-    xyz = ops.las_scale(torch.from_numpy(data.XYZ).to(dev), data.header.scales, data.header.offsets)
-    return xyz.cpu().numpy()
+    hdr, XYZ = _las.read_device(las_path, dev)
+    if XYZ.shape[0] == 0:
+        return np.zeros((0, 3))
+    return ops.las_scale(XYZ, hdr.scales, hdr.offsets).cpu().numpy()
 
 
 def extract_and_visualize_towers_kuangxuan(las_path: str, tower_obbs: list,

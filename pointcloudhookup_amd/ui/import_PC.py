@@ -48,17 +48,15 @@ def run_voxel_downsampling(
     from .. import las as _las
     from .. import ops
 
-    data = _las.read(input_path)
-    total_points = len(data)
+    dev = torch.device(DEVICE)
+    hdr, XYZ = _las.read_device(input_path, dev)                      # records decoded on the GPU
+    total_points = int(XYZ.shape[0])
 
     if log_callback:
         log_callback(f"📂 原始点数: {total_points}")
         log_callback(f"✨ 开始下采样（voxel_size={voxel_size}, chunk_size={chunk_size}）")
 
-    hdr = data.header
-    dev = torch.device(DEVICE)
     if total_points:
-        XYZ = torch.from_numpy(data.XYZ).to(dev)
         xyz = ops.las_scale(XYZ, hdr.scales, hdr.offsets)            # chunk.x/.y/.z  (:47-48)
         del XYZ
         _, mean, _, offs = ops.voxel_downsample(xyz, float(voxel_size), int(chunk_size))

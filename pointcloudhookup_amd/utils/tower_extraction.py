@@ -54,13 +54,12 @@ def extract_towers(
         import torch
         from .. import las as _las
         from .. import ops, pipeline
-        data = _las.read(input_las_path)
         dev = torch.device(DEVICE)
-        XYZ = torch.from_numpy(data.XYZ).to(dev)
-        raw = ops.cast_f32(ops.las_scale(XYZ, data.header.scales, data.header.offsets))
+        hdr, XYZ = _las.read_device(input_las_path, dev)               # records decoded on the GPU
+        raw = ops.cast_f32(ops.las_scale(XYZ, hdr.scales, hdr.offsets))
         del XYZ
-        header_info = {"scales": data.header.scales, "offsets": data.header.offsets,
-                       "point_format": data.header.point_format, "version": data.header.version}
+        header_info = {"scales": hdr.scales, "offsets": hdr.offsets,
+                       "point_format": hdr.point_format, "version": hdr.version}
         log(f"✅ 点云读取完成，总点数: {raw.shape[0]}")
     except Exception as e:
         log(f"⚠️ 文件读取失败: {str(e)}")
