@@ -21,7 +21,8 @@ constexpr int DB_THREADS = 256;
 constexpr int DB_WAVES   = DB_THREADS / 64;
 constexpr int DB_ROWS    = 25;
 constexpr int INT_BIG    = 0x7fffffff;
-constexpr int DB_FEW_QUERIES = 24;   // below: candidate-parallel radius count, else query-parallel tiles
+constexpr int DB_FEW_QUERIES = 24;
+constexpr int DB_SEGS = 43;          // 9 inner + 9 + 9 end pieces of the near runs + 16 outer runs   // below: candidate-parallel radius count, else query-parallel tiles
 
 struct DbGrid {
     float   ox, oy, oz;          // grid origin (lower corner of the bounding box)
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
                                                         uint32_t* __restrict__ cell_ncore) {
     __shared__ RowSet rows[DB_WAVES];
     __shared__ __attribute__((aligned(16))) float4 tiles[DB_WAVES][64];
+    __shared__ uint32_t seg_a[DB_WAVES][DB_SEGS], seg_b[DB_WAVES][DB_SEGS];
     const int c = blockIdx.x * DB_WAVES + wave_id();
     if (c >= m) return;
     const int l = lane_id();
@@ -303,6 +305,30 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
         if (l == 0) cell_ncore[c] = 0;
         return;
     }
+    // candidate segments in nearest-first order: the 27-cell neighbourhood first (x-1..x+1 of the
+    // nine nearest runs), then the x-2 / x+2 ends of those runs, then the sixteen outer runs
+    uint32_t* sa = seg_a[wave_id()];
+    uint32_t* sb = seg_b[wave_id()];
+    {
+        const uint64_t xmask = (1ull << g.bx) - 1;
+        const int cx = (int)(cell_key[c] & xmask);
+        if (l < DB_ROWS) {
+            const int ca = rs->ca[l], cb = rs->cb[l];
+            if (l < 9) {
+                int ia = ca, ib = cb;
+                if (ca < cb) {
+                    if ((int)(cell_key[ca] & xmask) == cx - 2) ia = ca + 1;
+                    if (ib > ia && (int)(cell_key[cb - 1] & xmask) == cx + 2) ib = cb - 1;
+                }
+                sa[l] = cell_start[ia];      sb[l] = cell_start[ib];          // inner part
+                sa[9 + l] = cell_start[ca];  sb[9 + l] = cell_start[ia];      // x-2 end
+                sa[18 + l] = cell_start[ib]; sb[18 + l] = cell_start[cb];     // x+2 end
+            } else {
+                sa[18 + l] = cell_start[ca]; sb[18 + l] = cell_start[cb];     // outer runs: slots 27..42
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     uint32_t ncore = 0;
     if (cnt < DB_FEW_QUERIES) {
         // a handful of queries (cluster fringe): lanes sweep the candidates of one query at a
@@ -310,8 +336,8 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
         for (uint32_t q = s; q < e; ++q) {
             const float4 qp = pts[q];
             int count = 0;
-            for (int r = 0; r < DB_ROWS && count < g.min_samples; ++r) {
-                const uint32_t pa = cell_start[rs->ca[r]], pb = cell_start[rs->cb[r]];
+            for (int r = 0; r < DB_SEGS && count < g.min_samples; ++r) {
+                const uint32_t pa = sa[r], pb = sb[r];
                 for (uint32_t j0 = pa; j0 < pb && count < g.min_samples; j0 += 64) {
                     const uint32_t j = j0 + l;
                     bool hit = false;
@@ -335,12 +361,12 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
         int count = 0;
         unsigned long long active = __ballot(valid);        // queries still below min_samples
         int r = 0;
-        uint32_t j0 = cell_start[rs->ca[0]];
+        uint32_t j0 = sa[0];
         // phase 1: all queries against one staged candidate tile at a time, while enough of
         // them are still counting to keep the lanes busy
-        while (r < DB_ROWS && __popcll(active) >= DB_FEW_QUERIES / 2) {
-            const uint32_t pb = cell_start[rs->cb[r]];
-            if (j0 >= pb) { ++r; if (r < DB_ROWS) j0 = cell_start[rs->ca[r]]; continue; }
+        while (r < DB_SEGS && __popcll(active) >= DB_FEW_QUERIES / 2) {
+            const uint32_t pb = sb[r];
+            if (j0 >= pb) { ++r; if (r < DB_SEGS) j0 = sa[r]; continue; }
             const int nj = (int)((pb - j0) < 64u ? (pb - j0) : 64u);
             float4 P;
             P.x = P.y = P.z = 3.0e38f; P.w = 0.0f;         // padding: squared distance overflows to +inf
@@ -365,9 +391,9 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
             int cq = __shfl(count, ql, 64);
             int rr = r;
             uint32_t jj = j0;
-            while (rr < DB_ROWS && cq < g.min_samples) {
-                const uint32_t pb = cell_start[rs->cb[rr]];
-                if (jj >= pb) { ++rr; if (rr < DB_ROWS) jj = cell_start[rs->ca[rr]]; continue; }
+            while (rr < DB_SEGS && cq < g.min_samples) {
+                const uint32_t pb = sb[rr];
+                if (jj >= pb) { ++rr; if (rr < DB_SEGS) jj = sa[rr]; continue; }
                 const uint32_t j = jj + l;
                 bool hit = false;
                 if (j < pb) hit = db_within2(qp, pts[j], g);
@@ -414,6 +440,10 @@ __global__ __launch_bounds__(DB_THREADS) void db_cellbox_k(const float4* __restr
 }
 
 // ---- union-find over cells (hook larger root under smaller; lock free) ------------------
+// Invariant: parent[x] <= x, only roots (parent[x] == x) are ever hooked, and only by a CAS, so
+// every value ever stored in parent[x] is an ancestor of x.  Loads bypass the (incoherent) L1;
+// path compression is a PLAIN store of an ancestor - racing writers all write ancestors, and a
+// stale read merely costs an extra hop or a failed CAS, whose return value is the truth.
 __device__ __forceinline__ int uf_load(int* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -421,12 +451,13 @@ __device__ __forceinline__ int uf_find(int* __restrict__ parent, int x) {
     int p = uf_load(&parent[x]);
     while (p != x) {
         const int gp = uf_load(&parent[p]);
-        if (gp != p) atomicMin(&parent[x], gp);     // path halving; only ever moves x to an ancestor
+        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         x = p;
         p = gp;
     }
     return x;
 }
+// a, b: any members (ideally already roots) of the two sets
 __device__ __forceinline__ void uf_union(int* __restrict__ parent, int a, int b) {
     for (;;) {
         a = uf_find(parent, a);
@@ -435,6 +466,7 @@ __device__ __forceinline__ void uf_union(int* __restrict__ parent, int a, int b)
         if (a < b) { const int t = a; a = b; b = t; }   // a > b: hook a under b
         const int old = atomicCAS(&parent[a], a, b);
         if (old == a) return;
+        a = old;                                          // somebody hooked a first: follow it
     }
 }
 
@@ -510,9 +542,11 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4*
             const int src = (int)__builtin_ctzll(todo);
             todo &= todo - 1;
             const int Bs = __builtin_amdgcn_readlane(B, src);
-            int same = 0;                                  // united meanwhile through another cell?
-            if (l == 0) same = uf_find(parent, A) == uf_find(parent, Bs);
-            if (__builtin_amdgcn_readfirstlane(same)) continue;
+            if (ROUND == 1) {                              // united meanwhile through another cell?
+                int same = 0;
+                if (l == 0) same = uf_find(parent, A) == uf_find(parent, Bs);
+                if (__builtin_amdgcn_readfirstlane(same)) continue;
+            }
             const uint32_t bs = cell_start[Bs], be = cell_start[Bs + 1];
             const bool b_dense = cell_ncore[Bs] == (be - bs);
             const float* boxB = cell_box + 6 * (int64_t)Bs;
@@ -538,7 +572,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_flatten_k(int* __restrict__ par
     const int c = blockIdx.x * DB_THREADS + threadIdx.x;
     if (c >= m) return;
     const int r = uf_find(parent, c);
-    if (r != c) atomicMin(&parent[c], r);
+    if (r != c) parent[c] = r;
 }
 
 // root of every core cell + smallest original row among the component's core points
