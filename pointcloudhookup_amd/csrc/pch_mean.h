@@ -9,6 +9,7 @@ struct MsWs {
     int*       stats;            // [3][4]: level-2 batches, -, exactly added blocks, descents
     MsHdr     *hdr, *hdr2;
     long long *rows, *rows2;
+    uint32_t*  fix;              // [3][nb][24] sparse-tie adjustments (adj0 | adj1 << 16)
 };
 void ms_plan(Arena& a, int64_t n, MsWs& w);
 // centroid[3] = np.mean(xyz, axis=0) (float32).  zcol (optional, n floats) receives a copy of

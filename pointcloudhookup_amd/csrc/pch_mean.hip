@@ -28,15 +28,18 @@ constexpr int MSB       = 1024;    // points per summary block (one wave, 16 per
 constexpr int MS_PER    = 16;
 constexpr int MS_CAND   = 24;
 constexpr int MS_ROW    = MS_CAND + 1;      // level-1 row: S[24], A0
-constexpr int MS_ROW2   = 2 * MS_CAND;      // level-2 row: S[24], A[24]
+constexpr int MS_ROW2   = 3 * MS_CAND;      // level-2 row: N0[24], N1[24] (net per incoming parity), A[24]
 constexpr int MS_WAVES  = 4;
 constexpr uint32_t MS_NONFINITE = 1u, MS_ALLZERO = 2u;
+constexpr int MS_FIX_FROM = 11;     // sparse-tie fix-up for candidates >= this ...
+constexpr int MS_FIX_MAX  = 8;      // ... holding at most this many tie elements
 
 struct MsHdr { int emax; uint32_t tie; uint32_t flags; uint32_t pad; };
 
 __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __restrict__ xyz, int64_t n,
                                                              int64_t nb, MsHdr* __restrict__ hdr,
                                                              long long* __restrict__ rows,
+                                                             uint32_t* __restrict__ fix,
                                                              float* __restrict__ zcol) {
     __shared__ __attribute__((aligned(16))) float lds[MS_WAVES][MSB * 3];
     const int64_t blk = (int64_t)blockIdx.x * MS_WAVES + wave_id();
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
 #pragma unroll
         for (int j = 0; j < MS_CAND; ++j) acc[j] = 0;
         uint32_t tie = 0;
+        uint32_t jtp[MS_PER / 4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // tie candidate per element
         int A0 = 0;
         if (!nonfinite && mx != 0) {
 #pragma unroll
@@ -103,7 +107,10 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
                     const int xe = (int)(u >> 23);
                     const uint32_t ma = (u & 0x7FFFFFu) | (xe ? 0x800000u : 0u);
                     const int jt = (xe ? xe : 1) - 150 + (__ffs((int)ma) - 1) + 1;
-                    tie |= (jt >= 0 && jt < MS_CAND) ? (1u << jt) : 0u;
+                    if (jt >= 0 && jt < MS_CAND) {
+                        tie |= 1u << jt;
+                        jtp[i >> 2] = (jtp[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | ((uint32_t)jt << (8 * (i & 3)));
+                    }
                 }
                 acc[0] += (uint32_t)(int)rintf(x);
 #pragma unroll
@@ -122,6 +129,46 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) tie |= __shfl_xor(tie, o, 64);
+        // ---- sparse ties (candidates >= MS_FIX_FROM with at most MS_FIX_MAX tie elements): every tie
+        // leaves the running mantissa EVEN, and before it the parity is (incoming parity) ^ (parity of
+        // the increments in front of it), which a few ballots give.  So the block's net increment is
+        // known for both incoming parities: S_j + adj0 / S_j + adj1 (S_j uses the nearest-even value
+        // v of every tie element; a tie met at odd parity takes the other neighbour, v +- 1).
+        uint32_t myfix = 0;                                    // lane j keeps (adj0 & 0xFFFF) | adj1 << 16
+        {
+            uint32_t todo = tie & ~((1u << MS_FIX_FROM) - 1u);
+            while (todo) {
+                const int j = __ffs((int)todo) - 1;
+                todo &= todo - 1;
+                int nt = 0;
+#pragma unroll
+                for (int i = 0; i < MS_PER; ++i)
+                    nt += (int)__popcll(__ballot(((jtp[i >> 2] >> (8 * (i & 3))) & 0xFFu) == (uint32_t)j));
+                if (nt > MS_FIX_MAX) continue;
+                const float magic = ldexpf(1.5f, 23 + j);
+                int par = 0, adj0 = 0, adj1 = 0, pa0 = 0, pa1 = 0;
+#pragma unroll
+                for (int i = 0; i < MS_PER; ++i) {
+                    const float x = ldexpf(a[i], 22 - emax);
+                    const float t = x + magic;                  // nearest-even multiple of 2^j
+                    const float v = t - magic;                  // exact
+                    const unsigned long long low = __ballot((__float_as_uint(t) & 1u) != 0u);
+                    unsigned long long tb = __ballot(((jtp[i >> 2] >> (8 * (i & 3))) & 0xFFu) == (uint32_t)j);
+                    const int dirl = (v < x) ? 1 : -1;          // the other neighbour of a tie: v+2^j or v-2^j
+                    while (tb) {
+                        const int lt = (int)__builtin_ctzll(tb);
+                        tb &= tb - 1;
+                        const int pre = par ^ (int)(__popcll(low & ((1ull << lt) - 1ull)) & 1);
+                        const int dir = __builtin_amdgcn_readlane(dirl, lt);
+                        if ((0 ^ pre ^ pa0) & 1) { adj0 += dir; pa0 ^= 1; }
+                        if ((1 ^ pre ^ pa1) & 1) { adj1 += dir; pa1 ^= 1; }
+                    }
+                    par ^= (int)(__popcll(low) & 1);
+                }
+                tie &= ~(1u << j);                             // resolved: no longer "unknown"
+                if (l == j) myfix = ((uint32_t)adj0 & 0xFFFFu) | ((uint32_t)adj1 << 16);
+            }
+        }
         const long long A0w = wave_reduce_add((long long)A0);
         // transposed reduction: 24 -> 12 -> 6 -> 3 values per lane while summing over the lane
         // bits 5,4,3 (|partial| <= 2^30 stays in 32 bit), then three 64-bit butterfly steps
@@ -149,6 +196,7 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
 #pragma unroll
             for (int i = 0; i < 3; ++i) rows[row * MS_ROW + j0 + i] = t[i];
         }
+        if (l < MS_CAND) fix[row * MS_CAND + l] = myfix;
         if (l == 0) {
             rows[row * MS_ROW + MS_CAND] = A0w;
             MsHdr h;
@@ -259,11 +307,13 @@ __device__ __forceinline__ uint32_t ms_block_exact(const float* __restrict__ xyz
     return sb;
 }
 
-// ---- level 2: one row per 64 level-1 blocks (65 536 points).  Sums and bounds are additive,
-// so a parent row is the sum of its children's rows taken at the same absolute binade; a child
-// contributes nothing to candidates 24 or more binades above its own largest element.
+// ---- level 2: one row per 64 level-1 blocks (65 536 points).  Bounds are additive; the net
+// increments are summed when no child depends on the incoming parity and composed IN ORDER
+// ((f then g)(p) = f(p) + g((p + f(p)) & 1)) when one does.  A child contributes nothing to
+// candidates 24 or more binades above its own largest element.
 __global__ __launch_bounds__(256) void ms_level2_k(const MsHdr* __restrict__ hdr,
-                                                   const long long* __restrict__ rows, int64_t nb,
+                                                   const long long* __restrict__ rows,
+                                                   const uint32_t* __restrict__ fix, int64_t nb,
                                                    int64_t nb2, MsHdr* __restrict__ hdr2,
                                                    long long* __restrict__ rows2) {
     const int64_t w = (int64_t)blockIdx.x * 4 + wave_id();
@@ -283,24 +333,36 @@ __global__ __launch_bounds__(256) void ms_level2_k(const MsHdr* __restrict__ hdr
     uint32_t tie2 = 0;
     const int shift = emax2 - h.emax;                      // >= 0 for non-zero children
     const bool live = valid && !zero && !(h.flags & MS_NONFINITE);
-    const long long* row = rows + ((int64_t)c * nb + (valid ? bb : 0)) * MS_ROW;
+    const int64_t rowi = (int64_t)c * nb + (valid ? bb : 0);
+    const long long* row = rows + rowi * MS_ROW;
     const long long A0 = live ? row[MS_CAND] : 0;
     for (int j2 = 0; j2 < MS_CAND; ++j2) {
         const int j = j2 + shift;
-        long long S = 0, A = 0;
+        long long n0 = 0, n1 = 0, A = 0;
         bool tie = false;
         if (live && j < MS_CAND) {
-            S = row[j];
+            const long long S = row[j];
+            const uint32_t f = fix[rowi * MS_CAND + j];
+            n0 = S + (long long)(short)(f & 0xFFFFu);
+            n1 = S + (long long)(short)(f >> 16);
             A = (A0 >> j) + MSB;                           // >= sum |d_i| of the child at this binade
             tie = (h.tie >> j) & 1u;
         }
-        S = wave_reduce_add(S);
+        if (__ballot(n0 != n1)) {
+            ms_scan_pairs(n0, n1);                          // lane 63 holds the composition of all children
+            n0 = ms_readlane64(n0, 63);
+            n1 = ms_readlane64(n1, 63);
+        } else {
+            n0 = wave_reduce_add(n0);
+            n1 = n0;
+        }
         A = wave_reduce_add(A);
         if (__ballot(tie)) tie2 |= 1u << j2;
         if (l == 0) {
             const int64_t at2 = ((int64_t)c * nb2 + g) * MS_ROW2;
-            rows2[at2 + j2] = S;
-            rows2[at2 + MS_CAND + j2] = A;
+            rows2[at2 + j2] = n0;
+            rows2[at2 + MS_CAND + j2] = n1;
+            rows2[at2 + 2 * MS_CAND + j2] = A;
         }
     }
     if (l == 0) {
@@ -314,8 +376,8 @@ __global__ __launch_bounds__(256) void ms_level2_k(const MsHdr* __restrict__ hdr
 }
 
 struct MsTables {
-    const MsHdr* hdr; const long long* rows; int64_t nb;        // level 1
-    const MsHdr* hdr2; const long long* rows2; int64_t nb2;     // level 2
+    const MsHdr* hdr; const long long* rows; const uint32_t* fix; int64_t nb;   // level 1
+    const MsHdr* hdr2; const long long* rows2; int64_t nb2;                     // level 2
 };
 
 // 0: s cannot change, 1: integer increments with table bounds, 2: unknown at this binade
@@ -328,13 +390,41 @@ __device__ __forceinline__ int ms_classify(const MsHdr& h, bool valid, bool s_in
     return ((h.tie >> j) & 1u) ? 2 : 1;
 }
 
-// table entry -> (net increment of |s|, lowest / highest possible prefix) for the sign of s
-__device__ __forceinline__ void ms_bounds(long long S, long long A, bool s_neg, long long& net,
-                                          long long& lo, long long& hi) {
-    const long long up = (A + S + 1) >> 1, dn = (A - S + 1) >> 1;   // sum of positive / negative parts
-    net = s_neg ? -S : S;
-    hi = s_neg ? dn : up;
-    lo = -(s_neg ? up : dn);
+// what a lane knows about its table row at the current binade: net increment of |s| for either
+// parity of the incoming mantissa, and an interval that contains every prefix
+struct MsEntry { long long n0, n1, lo, hi; };
+__device__ __forceinline__ MsEntry ms_entry(long long p0, long long p1, long long A, bool s_neg) {
+    // p0/p1: net increments in the s > 0 frame; for s < 0 both flip sign (ties included)
+    const long long smax = p0 > p1 ? p0 : p1, smin = p0 < p1 ? p0 : p1;
+    const long long up = ((A + smax + 1) >> 1) + MS_FIX_MAX, dn = ((A - smin + 1) >> 1) + MS_FIX_MAX;
+    MsEntry e;
+    e.n0 = s_neg ? -p0 : p0;
+    e.n1 = s_neg ? -p1 : p1;
+    e.hi = s_neg ? dn : up;
+    e.lo = -(s_neg ? up : dn);
+    return e;
+}
+
+// one step of the certified walk over up to 64 rows held one per lane: scans the increments of
+// the lanes >= start, returns the first lane whose certificate fails (or `count`) and advances
+// m_cur / sb over the certified lanes in front of it
+__device__ __forceinline__ int ms_certify(int cls, const MsEntry& e, bool valid, int start, int count,
+                                          bool s_norm, long long& m_cur, uint32_t& sb) {
+    const int l = lane_id();
+    long long c0 = l >= start ? e.n0 : 0ll, c1 = l >= start ? e.n1 : 0ll;
+    ms_scan_pairs(c0, c1);                              // inclusive: increment through lane l
+    const int pc = (int)(m_cur & 1);
+    long long e0 = __shfl_up(c0, 1, 64), e1 = __shfl_up(c1, 1, 64);
+    if (l == 0) { e0 = 0; e1 = 0; }
+    const long long m_in = m_cur + (pc ? e1 : e0);
+    const bool ok = cls == 0 || (cls == 1 && m_in + e.hi + 1 < (1ll << 24) && m_in + e.lo - 1 >= (1ll << 23));
+    const unsigned long long fail = __ballot(valid && l >= start && !ok);
+    const int f = fail ? (int)__builtin_ctzll(fail) : count;
+    if (f > start && s_norm) {                          // advance over the certified lanes
+        m_cur += ms_readlane64(pc ? c1 : c0, f - 1);
+        sb = (sb & 0xFF800000u) | ((uint32_t)m_cur & 0x7FFFFFu);
+    }
+    return fail ? f : -1;
 }
 
 // Adds the level-1 blocks [first, first+count), count <= 64, to the running sum `sb` (bits).
@@ -357,25 +447,21 @@ __device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ x
         if (valid) h = T.hdr[(int64_t)c * T.nb + bb];
         int j;
         const int cls = ms_classify(h, valid, s_inf, s_norm, E, j);
-        long long net = 0, lo = 0, hi = 0;
+        MsEntry en;
+        en.n0 = en.n1 = en.lo = en.hi = 0;
         if (cls == 1) {
-            const long long* row = T.rows + ((int64_t)c * T.nb + bb) * MS_ROW;
-            ms_bounds(row[j], (row[MS_CAND] >> j) + MSB, s_neg, net, lo, hi);
+            const int64_t rowi = (int64_t)c * T.nb + bb;
+            const long long* row = T.rows + rowi * MS_ROW;
+            const long long S = row[j];
+            const uint32_t f = T.fix[rowi * MS_CAND + j];
+            en = ms_entry(S + (long long)(short)(f & 0xFFFFu), S + (long long)(short)(f >> 16),
+                          (row[MS_CAND] >> j) + MSB, s_neg);
         }
         int start = done;                               // first unresolved lane
         long long m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);   // mantissa entering `start`
         for (;;) {
-            const long long incl = wave_scan_incl(l >= start ? net : 0ll);
-            const long long m_in = m_cur + incl - (l >= start ? net : 0ll);
-            const bool ok = cls == 0 || (cls == 1 && m_in + hi + 1 < (1ll << 24) && m_in + lo - 1 >= (1ll << 23));
-            const unsigned long long fail = __ballot(valid && l >= start && !ok);
-            const int f = fail ? (int)__builtin_ctzll(fail) : count;
-            if (f > start && s_norm) {                  // advance over the certified lanes
-                m_cur += ms_readlane64(incl, f - 1);
-                sb = (sb & 0xFF800000u) | ((uint32_t)m_cur & 0x7FFFFFu);
-            }
-            start = f;
-            if (!fail) { done = count; break; }
+            const int f = ms_certify(cls, en, valid, start, count, s_norm, m_cur, sb);
+            if (f < 0) { done = count; break; }
             // child f cannot be certified from the table at this binade: add it exactly
             ++n_exact;
             const uint32_t nsb = ms_block_exact(xyz, n, c, first + f, sb, stage);
@@ -415,26 +501,18 @@ __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, i
         if (valid) h = T.hdr2[(int64_t)c * T.nb2 + bb];
         int j;
         const int cls = ms_classify(h, valid, s_inf, s_norm, E, j);
-        long long net = 0, lo = 0, hi = 0;
+        MsEntry en;
+        en.n0 = en.n1 = en.lo = en.hi = 0;
         if (cls == 1) {
             const long long* row = T.rows2 + ((int64_t)c * T.nb2 + bb) * MS_ROW2;
-            ms_bounds(row[j], row[MS_CAND + j], s_neg, net, lo, hi);
+            en = ms_entry(row[j], row[MS_CAND + j], row[2 * MS_CAND + j], s_neg);
         }
         int start = 0;
         long long m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);
         bool reload = false;
         while (!reload) {
-            const long long incl = wave_scan_incl(l >= start ? net : 0ll);
-            const long long m_in = m_cur + incl - (l >= start ? net : 0ll);
-            const bool ok = cls == 0 || (cls == 1 && m_in + hi + 1 < (1ll << 24) && m_in + lo - 1 >= (1ll << 23));
-            const unsigned long long fail = __ballot(valid && l >= start && !ok);
-            const int f = fail ? (int)__builtin_ctzll(fail) : 64;
-            if (f > start && s_norm) {
-                m_cur += ms_readlane64(incl, f - 1);
-                sb = (sb & 0xFF800000u) | ((uint32_t)m_cur & 0x7FFFFFu);
-            }
-            start = f;
-            if (!fail) break;
+            const int f = ms_certify(cls, en, valid, start, 64, s_norm, m_cur, sb);
+            if (f < 0) break;
             // descend into the 64 children of row b+f
             ++n_desc;
             const int64_t first = (b + f) * 64;
@@ -492,6 +570,7 @@ void ms_plan(Arena& a, int64_t n, MsWs& w) {
     w.stats = a.take<int>(16);
     w.hdr = a.take<MsHdr>(3 * nb);
     w.rows = a.take<long long>(3 * nb * MS_ROW);
+    w.fix = a.take<uint32_t>(3 * nb * MS_CAND);
     w.hdr2 = a.take<MsHdr>(3 * nb2);
     w.rows2 = a.take<long long>(3 * nb2 * MS_ROW2);
 }
@@ -502,13 +581,13 @@ int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zco
     const int64_t nb2 = ceil_div(nb, 64);
     if (n > 0) {
         PCH_LAUNCH("mean_summary", ms_summary_k, dim3((unsigned)ceil_div(nb, MS_WAVES)), dim3(64 * MS_WAVES),
-                   0, s, xyz, n, nb, w.hdr, w.rows, zcol);
+                   0, s, xyz, n, nb, w.hdr, w.rows, w.fix, zcol);
         if (ev_zcol) PCH_HIP_TRY(hipEventRecord(ev_zcol, s));
         PCH_LAUNCH("mean_level2", ms_level2_k, dim3((unsigned)ceil_div(3 * nb2, 4)), dim3(256), 0, s,
-                   (const MsHdr*)w.hdr, (const long long*)w.rows, nb, nb2, w.hdr2, w.rows2);
+                   (const MsHdr*)w.hdr, (const long long*)w.rows, (const uint32_t*)w.fix, nb, nb2, w.hdr2, w.rows2);
     }
     MsTables T;
-    T.hdr = w.hdr; T.rows = w.rows; T.nb = nb;
+    T.hdr = w.hdr; T.rows = w.rows; T.fix = w.fix; T.nb = nb;
     T.hdr2 = w.hdr2; T.rows2 = w.rows2; T.nb2 = nb2;
     PCH_LAUNCH("mean_walk", ms_walk_k, dim3(3), dim3(64), 0, s, xyz, n, T, out, w.stats);
     return PCH_OK;
