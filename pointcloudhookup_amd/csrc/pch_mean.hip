@@ -241,13 +241,14 @@ __device__ __forceinline__ int ms_pad(int i) { return i + (i >> 4); }   // LDS b
 // the sum, a binade or sign change, a non-finite value) is added element by element, and the
 // rest of the block is redone at the new binade.
 __device__ __forceinline__ uint32_t ms_block_exact(const float* __restrict__ xyz, int64_t n, int c,
-                                                   int64_t blk, uint32_t sb, float* stage) {
+                                                   int64_t blk, uint32_t sb, float* stage, int& serial_len) {
     const int l = lane_id();
     const int64_t p0 = blk * MSB;
     const int cnt = (int)((n - p0) < MSB ? (n - p0) : MSB);
     for (int i = l; i < cnt; i += 64) stage[ms_pad(i)] = xyz[3 * (p0 + i) + c];
     __syncthreads();
-    int pos = 0;
+    int pos = 0;                        // serial_len (kept across calls) grows while the parallel
+                                        // passes make little progress and falls back when they do
     while (pos < cnt) {
         const uint32_t ef = (sb >> 23) & 0xFFu;
         if (ef == 255u && (sb & 0x7FFFFFu)) break;                 // NaN is absorbing
@@ -295,11 +296,22 @@ __device__ __forceinline__ uint32_t ms_block_exact(const float* __restrict__ xyz
                 pos += MS_SEG * f;
             }
             if (!fail) break;                                      // whole remainder applied
+            // little progress (sum comparable to the elements: binade changes every few adds):
+            // lengthen the element-by-element stretch instead of paying a pass per 16 elements
+            serial_len = (f < 4) ? (serial_len < MSB ? serial_len * 4 : MSB) : MS_SEG;
         }
-        // add segment [pos, pos+16) one element at a time (all lanes redundantly, LDS broadcast)
+        // add [pos, pos+serial_len) one element at a time (all lanes redundantly, LDS broadcast)
         float s = __uint_as_float(sb);
-        const int end = pos + MS_SEG < cnt ? pos + MS_SEG : cnt;
-        for (int i = pos; i < end; ++i) s = s + stage[ms_pad(i)];
+        const int end = pos + serial_len < cnt ? pos + serial_len : cnt;
+        int i = pos;
+        for (; i + 16 <= end; i += 16) {                            // 16 LDS reads in flight per chain step
+            float a[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = stage[ms_pad(i + k)];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s = s + a[k];
+        }
+        for (; i < end; ++i) s = s + stage[ms_pad(i)];
         sb = __builtin_amdgcn_readfirstlane(__float_as_uint(s));
         pos = end;
     }
@@ -430,7 +442,7 @@ __device__ __forceinline__ int ms_certify(int cls, const MsEntry& e, bool valid,
 // Adds the level-1 blocks [first, first+count), count <= 64, to the running sum `sb` (bits).
 __device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ xyz, int64_t n, int c,
                                                      const MsTables& T, int64_t first, int count,
-                                                     uint32_t sb, float* stage, int& n_exact) {
+                                                     uint32_t sb, float* stage, int& n_exact, int& serial_len) {
     const int l = lane_id();
     int done = 0;                                       // children already added
     while (done < count) {
@@ -464,7 +476,7 @@ __device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ x
             if (f < 0) { done = count; break; }
             // child f cannot be certified from the table at this binade: add it exactly
             ++n_exact;
-            const uint32_t nsb = ms_block_exact(xyz, n, c, first + f, sb, stage);
+            const uint32_t nsb = ms_block_exact(xyz, n, c, first + f, sb, stage, serial_len);
             const bool same = ((nsb ^ sb) & 0xFF800000u) == 0 && s_norm;   // same sign and binade
             sb = nsb;
             start = f + 1;
@@ -486,6 +498,7 @@ __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, i
     uint32_t sb = 0;                                   // bits of the running sum (+0.0)
     int64_t b = 0;                                     // next level-2 row
     int n_exact = 0, n_batches = 0, n_desc = 0;
+    int serial_len = MS_SEG;
     while (b < T.nb2) {
         ++n_batches;
         const uint32_t ef = (sb >> 23) & 0xFFu;
@@ -517,7 +530,7 @@ __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, i
             ++n_desc;
             const int64_t first = (b + f) * 64;
             const int count = (int)((T.nb - first) < 64 ? (T.nb - first) : 64);
-            const uint32_t nsb = ms_walk_children(xyz, n, c, T, first, count, sb, stage, n_exact);
+            const uint32_t nsb = ms_walk_children(xyz, n, c, T, first, count, sb, stage, n_exact, serial_len);
             const bool same = ((nsb ^ sb) & 0xFF800000u) == 0 && s_norm;
             sb = nsb;
             start = f + 1;
