@@ -169,6 +169,9 @@ int pch_segment_by_label(const int32_t* labels, const float* xyz, int64_t n,
  * kernels launched by this thread's pch_* calls since the previous pch_get_profile /
  * pch_set_profiling call.  Returns the number of entries.  (synchronises) */
 void pch_set_profiling(int enable);
+/* restrict the recording to a comma separated list of kernel names (NULL or "" = all): keeps the
+ * host cost of the event records out of a timed region that only needs its heavy kernels */
+void pch_set_profiling_filter(const char* names);
 int  pch_get_profile(int cap, char names[][48], float* ms, int* launches);
 
 #ifdef __cplusplus

@@ -48,6 +48,7 @@ _SIGS = {
     "pch_segment_by_label_ws_bytes": (_sz, [_i64, _i32]),
     "pch_segment_by_label": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pch_set_profiling": (None, [C.c_int]),
+    "pch_set_profiling_filter": (None, [C.c_char_p]),
     "pch_get_profile": (C.c_int, [C.c_int, _vp, _vp, _vp]),
 }
 

@@ -64,12 +64,13 @@ struct Arena {
 // When enabled every PCH_LAUNCH is bracketed by hipEvents recorded on the launch stream.
 void prof_begin_call();                       // (records accumulate until collected)
 bool prof_enabled();
+bool prof_wanted(const char* name);             // name filter (pch_set_profiling_filter)
 void prof_pre(const char* name, hipStream_t s);
 void prof_post(hipStream_t s);
 
 #define PCH_LAUNCH(name, kernel, grid, block, shmem, stream, ...)                  \
     do {                                                                           \
-        const bool _prof = ::pch::prof_enabled();                                  \
+        const bool _prof = ::pch::prof_enabled() && ::pch::prof_wanted(name);            \
         if (_prof) ::pch::prof_pre(name, stream);                                  \
         hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);       \
         if (_prof) ::pch::prof_post(stream);                                       \

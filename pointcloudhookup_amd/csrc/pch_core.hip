@@ -42,7 +42,16 @@ constexpr size_t PROF_MAX_RECORDS = 16384;
 
 void prof_begin_call() {}
 
+static thread_local std::vector<std::string> g_filter;   // empty: every kernel
+
 bool prof_enabled() { return g_prof_on && g_recs.size() < PROF_MAX_RECORDS; }
+
+bool prof_wanted(const char* name) {
+    if (g_filter.empty()) return true;
+    for (auto& f : g_filter)
+        if (f == name) return true;
+    return false;
+}
 
 static void prof_clear() {
     for (auto& r : g_recs) {
@@ -80,6 +89,21 @@ int pch_device_count(void) {
 void pch_set_profiling(int enable) {
     pch::g_prof_on = enable != 0;
     pch::prof_clear();
+}
+
+void pch_set_profiling_filter(const char* names) {
+    pch::g_filter.clear();
+    if (!names) return;
+    std::string cur;
+    for (const char* p = names;; ++p) {
+        if (*p == ',' || *p == 0) {
+            if (!cur.empty()) pch::g_filter.push_back(cur);
+            cur.clear();
+            if (*p == 0) break;
+        } else {
+            cur.push_back(*p);
+        }
+    }
 }
 
 int pch_get_profile(int cap, char names[][48], float* ms, int* launches) {

@@ -58,8 +58,12 @@ def release_workspace():
     _tls.ws = {}
 
 
-def set_profiling(enable):
-    _lib.lib().pch_set_profiling(1 if enable else 0)
+def set_profiling(enable, only=None):
+    """Enables per-kernel hipEvent timing inside the library; ``only`` (iterable of kernel names)
+    restricts the recording so that the host cost of the event records stays negligible."""
+    L = _lib.lib()
+    L.pch_set_profiling_filter(",".join(only).encode() if only else None)
+    L.pch_set_profiling(1 if enable else 0)
 
 
 def get_profile():
