@@ -14,6 +14,7 @@ namespace pch {
 // selected order statistics only.
 // =====================================================================================
 constexpr int SEL_BINS = 4096;
+constexpr int SEL_TILE = 4096;          // values per workgroup trip in the histogram passes
 
 struct SelState {
     unsigned long long rank;       // remaining rank inside the current prefix
@@ -52,11 +53,7 @@ __global__ __launch_bounds__(256) void sel_hist_k(const float* __restrict__ base
     __syncthreads();
     const uint32_t prefix = st->prefix;
     unsigned long long nans = 0;
-    const int64_t span = (int64_t)gridDim.x * 256;
-    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += span) {     // wave-uniform trip count
-        const int64_t i = i0 + threadIdx.x;
-        const bool in = i < n;
-        const float v = in ? base[i * stride] : 0.0f;
+    auto take = [&](bool in, float v) {
         const uint32_t k = sel_key(v);
         if (PASS == 0) {
             sel_hist_add(h, in, k >> 20);
@@ -65,6 +62,27 @@ __global__ __launch_bounds__(256) void sel_hist_k(const float* __restrict__ base
             sel_hist_add(h, in && (k >> 20) == prefix, (k >> 8) & 0xFFFu);
         } else {
             sel_hist_add(h, in && (k >> 8) == prefix, k & 0xFFu);
+        }
+    };
+    // a workgroup takes tiles of 4096 values; on a contiguous, 16-byte aligned column every thread
+    // keeps four float4 loads in flight (the histogram update behind a load is a dependent chain)
+    const int64_t span = (int64_t)gridDim.x * SEL_TILE;
+    const bool vec = stride == 1 && (reinterpret_cast<uintptr_t>(base) & 15u) == 0;
+    for (int64_t t0 = (int64_t)blockIdx.x * SEL_TILE; t0 < n; t0 += span) {    // wave-uniform trip count
+        if (vec && t0 + SEL_TILE <= n) {
+            const float4* b4 = reinterpret_cast<const float4*>(base + t0);
+            float4 q[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q[r] = b4[r * 256 + threadIdx.x];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { take(true, q[r].x); take(true, q[r].y); take(true, q[r].z); take(true, q[r].w); }
+        } else {
+#pragma unroll 4
+            for (int r = 0; r < SEL_TILE / 256; ++r) {
+                const int64_t i = t0 + r * 256 + threadIdx.x;
+                const bool in = i < n;
+                take(in, in ? base[i * stride] : 0.0f);
+            }
         }
     }
     __syncthreads();
@@ -129,9 +147,26 @@ __global__ __launch_bounds__(256) void sel_next_k(const float* __restrict__ base
     if (st->need_next == 0) return;
     const uint32_t v0 = st->v0key;
     uint32_t best = 0xFFFFFFFFu;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const uint32_t k = sel_key(base[i * stride]);
+    auto take = [&](float v) {
+        const uint32_t k = sel_key(v);
         if (k > v0 && k < best) best = k;
+    };
+    const int64_t span = (int64_t)gridDim.x * SEL_TILE;
+    const bool vec = stride == 1 && (reinterpret_cast<uintptr_t>(base) & 15u) == 0;
+    for (int64_t t0 = (int64_t)blockIdx.x * SEL_TILE; t0 < n; t0 += span) {
+        if (vec && t0 + SEL_TILE <= n) {
+            const float4* b4 = reinterpret_cast<const float4*>(base + t0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 q = b4[r * 256 + threadIdx.x];
+                take(q.x); take(q.y); take(q.z); take(q.w);
+            }
+        } else {
+            for (int r = 0; r < SEL_TILE / 256; ++r) {
+                const int64_t i = t0 + r * 256 + threadIdx.x;
+                if (i < n) take(base[i * stride]);
+            }
+        }
     }
     best = wave_reduce_min(best);
     if (lane_id() == 0 && best != 0xFFFFFFFFu) atomicMin(&st->next_min, best);
@@ -200,8 +235,8 @@ static int select_passes(const float* base, int64_t n, int64_t stride, double q_
     PCH_HIP_TRY(hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * SEL_BINS, s));
     PCH_HIP_TRY(hipMemsetAsync(w.st, 0, sizeof(SelState), s));
     PCH_LAUNCH("sel_init", sel_init_k, dim3(1), dim3(1), 0, s, w.st, (unsigned long long)pi.k0);
-    int64_t gb = ceil_div(n, 256 * 16);
-    if (gb > 4096) gb = 4096;
+    int64_t gb = ceil_div(n, SEL_TILE);
+    if (gb > 2048) gb = 2048;
     if (gb < 1) gb = 1;
     const dim3 grid((unsigned)gb), blk(256);
     PCH_LAUNCH("sel_hist0", sel_hist_k<0>, grid, blk, 0, s, base, n, stride, w.st, w.hist);

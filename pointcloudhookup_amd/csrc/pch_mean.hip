@@ -36,13 +36,34 @@ constexpr int MS_FIX_MAX  = 8;      // ... holding at most this many tie element
 
 struct MsHdr { int emax; uint32_t tie; uint32_t flags; uint32_t pad; };
 
+// Table layout: candidate-major planes [column][slot][block], so that lanes that walk consecutive
+// blocks at (mostly) the same candidate read consecutive words.
+// level 1: slots 0..23 = S_j, slot 24 = A0 (MS_ROW planes); fix: 24 planes of uint32
+// level 2: slots 0..23 = N0_j, 24..47 = N1_j, 48..71 = A_j (MS_ROW2 planes)
+__host__ __device__ __forceinline__ int64_t ms_at(int c, int slot, int64_t blk, int64_t nblk, int planes) {
+    return ((int64_t)c * planes + slot) * nblk + blk;
+}
+
+// x/2^j is a rounding tie iff the lowest set bit of x is 2^(j-1): returns 1 << j for that j
+// (0 when x == 0 or x has bits below 2^-1; bits >= MS_CAND are masked off by the caller).
+// |x| < 2^23, so 2x converts to int exactly when it is an integer.
+__device__ __forceinline__ uint32_t ms_tie_bit(float x) {
+    const float y = x + x;
+    const int Y = (int)y;
+    return ((float)Y == y) ? (uint32_t)(Y & -Y) : 0u;
+}
+
 __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __restrict__ xyz, int64_t n,
                                                              int64_t nb, MsHdr* __restrict__ hdr,
                                                              long long* __restrict__ rows,
                                                              uint32_t* __restrict__ fix,
-                                                             float* __restrict__ zcol) {
+                                                             float* __restrict__ zcol, int xcd_remap) {
     __shared__ __attribute__((aligned(16))) float lds[MS_WAVES][MSB * 3];
-    const int64_t blk = (int64_t)blockIdx.x * MS_WAVES + wave_id();
+    // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of blocks so
+    // that the partial-line table writes of neighbouring blocks meet in ONE L2
+    int64_t wg = blockIdx.x;
+    if (xcd_remap) wg = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int64_t blk = wg * MS_WAVES + wave_id();
     if (blk >= nb) return;
     const int l = lane_id();
     const int64_t p0 = blk * MSB;
@@ -55,7 +76,7 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
 #pragma unroll
         for (int i = 0; i < 12; ++i) t4[i * 64 + l] = s4[i * 64 + l];
     } else {
-        for (int e = l; e < 3 * cnt; e += 64) tile[e] = src[e];
+        for (int e = l; e < 3 * MSB; e += 64) tile[e] = e < 3 * cnt ? src[e] : 0.0f;   // ragged tail: zero padded
     }
     __builtin_amdgcn_wave_barrier();
     if (zcol) {
@@ -71,19 +92,16 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         float a[MS_PER];
 #pragma unroll
         for (int i = 0; i < MS_PER; ++i) {
-            const int p = i * 64 + l;
-            a[i] = (p < cnt) ? tile[3 * p + c] : 0.0f;
+            a[i] = tile[3 * (i * 64 + l) + c];
         }
         uint32_t mx = 0;
-        bool bad = false;
 #pragma unroll
         for (int i = 0; i < MS_PER; ++i) {
             const uint32_t u = __float_as_uint(a[i]) & 0x7FFFFFFFu;
             mx = u > mx ? u : mx;
-            bad |= (u >= 0x7F800000u);
         }
-        mx = wave_reduce_max(mx);
-        const bool nonfinite = __ballot(bad) != 0;
+        mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_reduce_max(mx));
+        const bool nonfinite = mx >= 0x7F800000u;             // |bits| order: inf / NaN are the largest
         const int ef = (int)(mx >> 23);
         const int emax = (ef > 0 ? ef : 1) - 127;
         // S[j] = sum_i rne(x_i / 2^j).  For j >= 1, fl(x + 1.5*2^(23+j)) rounds x to a multiple of 2^j
@@ -95,23 +113,17 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
 #pragma unroll
         for (int j = 0; j < MS_CAND; ++j) acc[j] = 0;
         uint32_t tie = 0;
-        uint32_t jtp[MS_PER / 4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // tie candidate per element
         int A0 = 0;
-        if (!nonfinite && mx != 0) {
+        const bool live = !nonfinite && mx != 0;               // wave-uniform
+        int S[MS_CAND];
+#pragma unroll
+        for (int j = 0; j < MS_CAND; ++j) S[j] = 0;
+        if (live) {
 #pragma unroll
             for (int i = 0; i < MS_PER; ++i) {
                 const float x = ldexpf(a[i], 22 - emax);       // a / ulp(2^(emax+1)), |x| < 2^23, exact
-                const uint32_t u = __float_as_uint(x) & 0x7FFFFFFFu;
                 A0 += (int)ceilf(fabsf(x));
-                if (u) {                                       // x/2^j ties iff its lowest set bit is 2^(j-1)
-                    const int xe = (int)(u >> 23);
-                    const uint32_t ma = (u & 0x7FFFFFu) | (xe ? 0x800000u : 0u);
-                    const int jt = (xe ? xe : 1) - 150 + (__ffs((int)ma) - 1) + 1;
-                    if (jt >= 0 && jt < MS_CAND) {
-                        tie |= 1u << jt;
-                        jtp[i >> 2] = (jtp[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | ((uint32_t)jt << (8 * (i & 3)));
-                    }
-                }
+                tie |= ms_tie_bit(x);
                 acc[0] += (uint32_t)(int)rintf(x);
 #pragma unroll
                 for (int j = 1; j < MS_CAND; ++j) {
@@ -119,14 +131,14 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
                     acc[j] += __float_as_uint(x + magic);
                 }
             }
-        }
-        int S[MS_CAND];
-        S[0] = (int)acc[0];
+            S[0] = (int)acc[0];
 #pragma unroll
-        for (int j = 1; j < MS_CAND; ++j) {
-            const float magic = (float)(3ull << (22 + j));
-            S[j] = (!nonfinite && mx != 0) ? (int)(acc[j] - (uint32_t)MS_PER * __float_as_uint(magic)) : 0;
+            for (int j = 1; j < MS_CAND; ++j) {
+                const float magic = (float)(3ull << (22 + j));
+                S[j] = (int)(acc[j] - (uint32_t)MS_PER * __float_as_uint(magic));
+            }
         }
+        tie &= (1u << MS_CAND) - 1u;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) tie |= __shfl_xor(tie, o, 64);
         // ---- sparse ties (candidates >= MS_FIX_FROM with at most MS_FIX_MAX tie elements): every tie
@@ -143,7 +155,7 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
                 int nt = 0;
 #pragma unroll
                 for (int i = 0; i < MS_PER; ++i)
-                    nt += (int)__popcll(__ballot(((jtp[i >> 2] >> (8 * (i & 3))) & 0xFFu) == (uint32_t)j));
+                    nt += (int)__popcll(__ballot(ms_tie_bit(ldexpf(a[i], 22 - emax)) == (1u << j)));
                 if (nt > MS_FIX_MAX) continue;
                 const float magic = ldexpf(1.5f, 23 + j);
                 int par = 0, adj0 = 0, adj1 = 0, pa0 = 0, pa1 = 0;
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
                     const float t = x + magic;                  // nearest-even multiple of 2^j
                     const float v = t - magic;                  // exact
                     const unsigned long long low = __ballot((__float_as_uint(t) & 1u) != 0u);
-                    unsigned long long tb = __ballot(((jtp[i >> 2] >> (8 * (i & 3))) & 0xFFu) == (uint32_t)j);
+                    unsigned long long tb = __ballot(ms_tie_bit(x) == (1u << j));
                     const int dirl = (v < x) ? 1 : -1;          // the other neighbour of a tie: v+2^j or v-2^j
                     while (tb) {
                         const int lt = (int)__builtin_ctzll(tb);
@@ -194,11 +206,11 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         if ((l & 7) == 0) {
             const int j0 = (b5 ? 12 : 0) + (b4 ? 6 : 0) + (b3 ? 3 : 0);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) rows[row * MS_ROW + j0 + i] = t[i];
+            for (int i = 0; i < 3; ++i) rows[ms_at(c, j0 + i, blk, nb, MS_ROW)] = t[i];
         }
-        if (l < MS_CAND) fix[row * MS_CAND + l] = myfix;
+        if (l < MS_CAND) fix[ms_at(c, l, blk, nb, MS_CAND)] = myfix;
         if (l == 0) {
-            rows[row * MS_ROW + MS_CAND] = A0w;
+            rows[ms_at(c, MS_CAND, blk, nb, MS_ROW)] = A0w;
             MsHdr h;
             h.emax = emax;
             h.tie = tie;
@@ -345,16 +357,15 @@ __global__ __launch_bounds__(256) void ms_level2_k(const MsHdr* __restrict__ hdr
     uint32_t tie2 = 0;
     const int shift = emax2 - h.emax;                      // >= 0 for non-zero children
     const bool live = valid && !zero && !(h.flags & MS_NONFINITE);
-    const int64_t rowi = (int64_t)c * nb + (valid ? bb : 0);
-    const long long* row = rows + rowi * MS_ROW;
-    const long long A0 = live ? row[MS_CAND] : 0;
+    const int64_t cb = valid ? bb : 0;
+    const long long A0 = live ? rows[ms_at(c, MS_CAND, cb, nb, MS_ROW)] : 0;
     for (int j2 = 0; j2 < MS_CAND; ++j2) {
         const int j = j2 + shift;
         long long n0 = 0, n1 = 0, A = 0;
         bool tie = false;
         if (live && j < MS_CAND) {
-            const long long S = row[j];
-            const uint32_t f = fix[rowi * MS_CAND + j];
+            const long long S = rows[ms_at(c, j, cb, nb, MS_ROW)];
+            const uint32_t f = fix[ms_at(c, j, cb, nb, MS_CAND)];
             n0 = S + (long long)(short)(f & 0xFFFFu);
             n1 = S + (long long)(short)(f >> 16);
             A = (A0 >> j) + MSB;                           // >= sum |d_i| of the child at this binade
@@ -371,10 +382,9 @@ __global__ __launch_bounds__(256) void ms_level2_k(const MsHdr* __restrict__ hdr
         A = wave_reduce_add(A);
         if (__ballot(tie)) tie2 |= 1u << j2;
         if (l == 0) {
-            const int64_t at2 = ((int64_t)c * nb2 + g) * MS_ROW2;
-            rows2[at2 + j2] = n0;
-            rows2[at2 + MS_CAND + j2] = n1;
-            rows2[at2 + 2 * MS_CAND + j2] = A;
+            rows2[ms_at(c, j2, g, nb2, MS_ROW2)] = n0;
+            rows2[ms_at(c, MS_CAND + j2, g, nb2, MS_ROW2)] = n1;
+            rows2[ms_at(c, 2 * MS_CAND + j2, g, nb2, MS_ROW2)] = A;
         }
     }
     if (l == 0) {
@@ -462,12 +472,10 @@ __device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ x
         MsEntry en;
         en.n0 = en.n1 = en.lo = en.hi = 0;
         if (cls == 1) {
-            const int64_t rowi = (int64_t)c * T.nb + bb;
-            const long long* row = T.rows + rowi * MS_ROW;
-            const long long S = row[j];
-            const uint32_t f = T.fix[rowi * MS_CAND + j];
+            const long long S = T.rows[ms_at(c, j, bb, T.nb, MS_ROW)];
+            const uint32_t f = T.fix[ms_at(c, j, bb, T.nb, MS_CAND)];
             en = ms_entry(S + (long long)(short)(f & 0xFFFFu), S + (long long)(short)(f >> 16),
-                          (row[MS_CAND] >> j) + MSB, s_neg);
+                          (T.rows[ms_at(c, MS_CAND, bb, T.nb, MS_ROW)] >> j) + MSB, s_neg);
         }
         int start = done;                               // first unresolved lane
         long long m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);   // mantissa entering `start`
@@ -517,8 +525,8 @@ __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, i
         MsEntry en;
         en.n0 = en.n1 = en.lo = en.hi = 0;
         if (cls == 1) {
-            const long long* row = T.rows2 + ((int64_t)c * T.nb2 + bb) * MS_ROW2;
-            en = ms_entry(row[j], row[MS_CAND + j], row[2 * MS_CAND + j], s_neg);
+            en = ms_entry(T.rows2[ms_at(c, j, bb, T.nb2, MS_ROW2)], T.rows2[ms_at(c, MS_CAND + j, bb, T.nb2, MS_ROW2)],
+                          T.rows2[ms_at(c, 2 * MS_CAND + j, bb, T.nb2, MS_ROW2)], s_neg);
         }
         int start = 0;
         long long m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);
@@ -593,8 +601,10 @@ int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zco
     const int64_t nb = n > 0 ? ceil_div(n, MSB) : 0;
     const int64_t nb2 = ceil_div(nb, 64);
     if (n > 0) {
-        PCH_LAUNCH("mean_summary", ms_summary_k, dim3((unsigned)ceil_div(nb, MS_WAVES)), dim3(64 * MS_WAVES),
-                   0, s, xyz, n, nb, w.hdr, w.rows, w.fix, zcol);
+        const int xcd_remap = 1;
+        const int64_t nwg = ceil_div(nb, MS_WAVES);
+        PCH_LAUNCH("mean_summary", ms_summary_k, dim3((unsigned)(xcd_remap ? (nwg + 7) / 8 * 8 : nwg)), dim3(64 * MS_WAVES),
+                   0, s, xyz, n, nb, w.hdr, w.rows, w.fix, zcol, xcd_remap);
         if (ev_zcol) PCH_HIP_TRY(hipEventRecord(ev_zcol, s));
         PCH_LAUNCH("mean_level2", ms_level2_k, dim3((unsigned)ceil_div(3 * nb2, 4)), dim3(256), 0, s,
                    (const MsHdr*)w.hdr, (const long long*)w.rows, (const uint32_t*)w.fix, nb, nb2, w.hdr2, w.rows2);
