@@ -27,12 +27,14 @@ constexpr int DB_SEGS = 43;          // 9 inner + 9 + 9 end pieces of the near r
 struct DbGrid {
     float   ox, oy, oz;          // grid origin (lower corner of the bounding box)
     double  cell;                // cell side s
+    double  inv_cell;            // 1/s: cell index = floor((x - origin) * inv_cell); the 2^-16 slack in s
+                                 // covers the rounding of this product (< 2^-21 cells for indices < 2^31)
     double  eps2;                // eps*eps (sklearn _dist_to_rdist)
     float   eps2_lo, eps2_hi;    // float32 pre-filter: d32 <= lo is surely inside, d32 >= hi surely outside
     int     bx, by, bz;          // key bits per axis
     int     mx, my, mz;          // largest valid cell coordinate per axis
     int64_t chunk_size;
-    int64_t trash_chunk;         // chunk id given to the points of chunks that hold NaN/inf
+    const uint32_t* chunk_bad;   // != 0: the chunk holds NaN/inf and stays noise as a whole
     int     min_samples;
 };
 
@@ -133,6 +135,20 @@ __global__ __launch_bounds__(DB_THREADS) void db_aabb_in_k(const float* __restri
     }
 }
 
+// Cell coordinates of a point: floor((x - origin) / s) per axis, as a product with 1/s in float64
+// (error < 2^-21 cells for indices < 2^31, covered by the 2^-16 slack in s).  false: outside the
+// grid (or NaN), coordinates 0.
+__device__ __forceinline__ bool db_cell_coords(const DbGrid& g, float x, float y, float z,
+                                               uint32_t& cx, uint32_t& cy, uint32_t& cz) {
+    const double fx = floor(((double)x - (double)g.ox) * g.inv_cell);
+    const double fy = floor(((double)y - (double)g.oy) * g.inv_cell);
+    const double fz = floor(((double)z - (double)g.oz) * g.inv_cell);
+    const bool ok = fx >= 0.0 && fx <= (double)g.mx && fy >= 0.0 && fy <= (double)g.my &&
+                    fz >= 0.0 && fz <= (double)g.mz;
+    cx = ok ? (uint32_t)fx : 0u; cy = ok ? (uint32_t)fy : 0u; cz = ok ? (uint32_t)fz : 0u;
+    return ok;
+}
+
 // ---- cell keys -----------------------------------------------------------------------
 __global__ __launch_bounds__(DB_THREADS) void db_keys_k(const float* __restrict__ xyz, int64_t n,
                                                         DbGrid g, const uint32_t* __restrict__ bad,
@@ -142,18 +158,13 @@ __global__ __launch_bounds__(DB_THREADS) void db_keys_k(const float* __restrict_
     const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
     if (i >= n) return;
     vals[i] = (uint32_t)i;
-    if (bad[i / g.chunk_size]) {                           // the whole chunk stays noise
-        keys[i] = db_pack(g, (uint64_t)g.trash_chunk, 0, 0, 0);
+    if (bad[i / g.chunk_size]) {                           // the whole chunk stays noise: one cell, never core
+        keys[i] = db_pack(g, (uint64_t)(i / g.chunk_size), 0, 0, 0);
         return;
     }
     const float x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    const double fx = floor(((double)x - (double)g.ox) / g.cell);
-    const double fy = floor(((double)y - (double)g.oy) / g.cell);
-    const double fz = floor(((double)z - (double)g.oz) / g.cell);
-    const bool ok = fx >= 0.0 && fx <= (double)g.mx && fy >= 0.0 && fy <= (double)g.my &&
-                    fz >= 0.0 && fz <= (double)g.mz;       // false for NaN / out of box
-    if (!ok) atomicOr(status, 1u);
-    const uint64_t cx = ok ? (uint64_t)fx : 0, cy = ok ? (uint64_t)fy : 0, cz = ok ? (uint64_t)fz : 0;
+    uint32_t cx, cy, cz;
+    if (!db_cell_coords(g, x, y, z, cx, cy, cz)) atomicOr(status, 1u);
     keys[i] = db_pack(g, (uint64_t)(i / g.chunk_size), cz, cy, cx);
 }
 
@@ -173,6 +184,215 @@ __global__ __launch_bounds__(DB_THREADS) void db_gather_k(const float* __restric
     p.w = __uint_as_float(o);
     pts[i] = p;
     head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+// ---- chunk-local sort: keys + sort + gather for one chunk per workgroup --------------------
+// Chunks are runs of consecutive input rows, so the chunk field of the key is already sorted;
+// only the cell bits (<= 32) need sorting, and only inside a chunk.  One 1024-thread workgroup
+// per chunk.  What moves through the LSD passes is the row itself, (x, y, z, original row) as one
+// float4: the cell key is a cheap function of (x, y, z) and is recomputed wherever a digit is
+// needed, so there is neither a key/index stream nor a random gather at the end (a 12-byte
+// gather costs a whole cache line).  Sweep H builds the digit histograms of every pass; pass 0
+// reads the input rows, the last pass writes the sorted rows and their full keys; a final sweep
+// flags the cell heads.  Replaces db_chunkbad, db_keys, every radix pass (histogram + 3 scan
+// kernels + scatter) and db_gather of the global path.
+struct Row3 { float x, y, z; };               // 4-byte aligned: loads as one global_load_dwordx3
+constexpr int CS_THREADS = 1024;
+constexpr int CS_WAVES   = CS_THREADS / 64;
+constexpr int CS_ROUNDS  = 4;
+constexpr int CS_TILE    = CS_THREADS * CS_ROUNDS;
+constexpr int CS_PASSES  = 4;
+constexpr int64_t CS_MAX_CHUNK = 1 << 17;     // larger chunks use the global sort
+
+// cell key of a row inside its chunk (0 when the row is outside the grid); ok = inside
+__device__ __forceinline__ uint32_t cs_cell_key(const DbGrid& g, float x, float y, float z, bool& ok) {
+    uint32_t cx, cy, cz;
+    ok = db_cell_coords(g, x, y, z, cx, cy, cz);
+    return (((cz << g.by) | cy) << g.bx) | cx;
+}
+
+__global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
+    const float* __restrict__ xyz, int64_t n, DbGrid g, uint32_t* __restrict__ bad,
+    float4* __restrict__ xbuf, float4* __restrict__ pts, uint64_t* __restrict__ keys_out,
+    uint32_t* __restrict__ head, uint32_t* __restrict__ status, int passes, int dbits,
+    unsigned long long* __restrict__ stamps) {
+#ifdef PCH_CS_STAMPS                                    // phase timing of one workgroup (tuning builds only)
+    int stamp_i = 0;
+#define CS_STAMP() if (stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) stamps[stamp_i++] = wall_clock64();
+#else
+#define CS_STAMP()
+#endif
+    CS_STAMP();
+    __shared__ uint32_t hist[CS_PASSES][256];
+    __shared__ uint32_t cnt[CS_WAVES][256];
+    __shared__ uint32_t off[CS_WAVES][256];
+    __shared__ uint32_t base[256];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t flags[2];                       // [0] chunk holds NaN/inf, [1] point outside the box
+    const int tid = threadIdx.x, w = wave_id(), l = lane_id();
+    const int64_t c = blockIdx.x;
+    const int64_t lo = c * g.chunk_size;
+    const int cn = (int)((n - lo) < g.chunk_size ? (n - lo) : g.chunk_size);
+    const uint32_t mask = (1u << dbits) - 1u;
+    const Row3* __restrict__ rows = reinterpret_cast<const Row3*>(xyz) + lo;
+    for (int j = tid; j < CS_PASSES * 256; j += CS_THREADS) (&hist[0][0])[j] = 0;
+    for (int j = tid; j < CS_WAVES * 256; j += CS_THREADS) (&cnt[0][0])[j] = 0;
+    if (tid < 2) flags[tid] = 0;
+    __syncthreads();
+    // ---- sweep H: digit histograms of every pass, NaN/inf and range checks
+    constexpr int HU = 8;                               // rows per thread in flight
+    for (int i0 = 0; i0 < cn; i0 += HU * CS_THREADS) {  // workgroup-uniform trip count
+        Row3 q[HU];
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            const int i = i0 + u * CS_THREADS + tid;
+            q[u] = rows[i < cn ? i : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            const bool in = i0 + u * CS_THREADS + tid < cn;
+            const bool fin = fabsf(q[u].x) < INFINITY && fabsf(q[u].y) < INFINITY && fabsf(q[u].z) < INFINITY;
+            bool ok;
+            const uint32_t k = cs_cell_key(g, q[u].x, q[u].y, q[u].z, ok);
+            if (in && !fin) flags[0] = 1u;
+            else if (in && !ok) flags[1] = 1u;
+            if (in)
+                for (int p = 0; p < passes; ++p) atomicAdd(&hist[p][(k >> (p * dbits)) & mask], 1u);
+        }
+    }
+    __syncthreads();
+    const bool isbad = flags[0] != 0;                   // the whole chunk stays noise: one cell, never core
+    CS_STAMP();
+    if (tid == 0) {
+        bad[c] = isbad ? 1u : 0u;
+        if (!isbad && flags[1]) atomicOr(status, 1u);
+    }
+    const int sh = g.bx + g.by + g.bz;
+    const uint64_t hi = sh < 64 ? ((uint64_t)c << sh) : 0ull;
+    if (isbad || passes == 0) {                         // rows stay where they are, all in cell 0
+        for (int i = tid; i < cn; i += CS_THREADS) {
+            const Row3 q = rows[i];
+            float4 o4;
+            o4.x = q.x; o4.y = q.y; o4.z = q.z; o4.w = __uint_as_float((uint32_t)(lo + i));
+            pts[lo + i] = o4;
+            keys_out[lo + i] = hi;
+            head[lo + i] = i == 0 ? 1u : 0u;
+        }
+        return;
+    }
+    const uint64_t lt = lanemask_lt();
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * dbits;
+        const bool last = p == passes - 1;
+        // pass p writes the sorted-rows array when an even number of passes follows, else the spare one
+        const float4* __restrict__ src = ((passes - p) & 1) ? xbuf + lo : pts + lo;     // what pass p-1 wrote
+        float4* __restrict__ dst = ((passes - 1 - p) & 1) ? xbuf + lo : pts + lo;
+        // exclusive scan of this pass' histogram
+        uint32_t hv = 0, incl = 0;
+        if (tid < 256) {
+            hv = hist[p][tid];
+            incl = wave_scan_incl(hv);
+            if (l == 63) wsum[w] = incl;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t b = incl - hv;
+            for (int w2 = 0; w2 < w; ++w2) b += wsum[w2];
+            base[tid] = b;
+        }
+        __syncthreads();
+        auto fetch = [&](int t0, float4 (&out)[CS_ROUNDS]) {
+            const int seg = t0 + w * (64 * CS_ROUNDS);
+#pragma unroll
+            for (int r = 0; r < CS_ROUNDS; ++r) {
+                const int i = seg + r * 64 + l;
+                const int j = i < cn ? i : 0;
+                if (p == 0) {
+                    const Row3 q = rows[j];
+                    out[r].x = q.x; out[r].y = q.y; out[r].z = q.z;
+                    out[r].w = __uint_as_float((uint32_t)(lo + j));
+                } else {
+                    out[r] = src[j];
+                }
+            }
+        };
+        float4 nxt[CS_ROUNDS];
+        fetch(0, nxt);
+        for (int t0 = 0; t0 < cn; t0 += CS_TILE) {
+            float4 row[CS_ROUNDS];
+            uint32_t key[CS_ROUNDS], rank[CS_ROUNDS];
+            const int seg = t0 + w * (64 * CS_ROUNDS);
+#pragma unroll
+            for (int r = 0; r < CS_ROUNDS; ++r) row[r] = nxt[r];
+            if (t0 + CS_TILE < cn) fetch(t0 + CS_TILE, nxt);        // in flight while this tile is ranked
+#pragma unroll
+            for (int r = 0; r < CS_ROUNDS; ++r) {
+                const bool valid = seg + r * 64 + l < cn;
+                bool ok;
+                key[r] = cs_cell_key(g, row[r].x, row[r].y, row[r].z, ok);
+                const uint32_t d = (key[r] >> shift) & mask;
+                uint64_t peers = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const bool bit = (d >> b) & 1u;
+                    const uint64_t m = __ballot(bit);
+                    peers &= bit ? m : ~m;
+                }
+                const uint32_t prior = cnt[w][d];
+                const uint32_t rk = (uint32_t)__popcll(peers & lt);
+                __builtin_amdgcn_wave_barrier();
+                if (valid && rk == 0) cnt[w][d] = prior + (uint32_t)__popcll(peers);
+                __builtin_amdgcn_wave_barrier();
+                rank[r] = prior + rk;
+            }
+            __syncthreads();
+            if (tid < 256) {                            // digit tid: waves in order, counters cleared for the next tile
+                uint32_t run = base[tid];
+#pragma unroll
+                for (int w2 = 0; w2 < CS_WAVES; ++w2) {
+                    const uint32_t cc = cnt[w2][tid];
+                    off[w2][tid] = run;
+                    cnt[w2][tid] = 0;
+                    run += cc;
+                }
+                base[tid] = run;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < CS_ROUNDS; ++r) {
+                if (seg + r * 64 + l < cn) {
+                    const uint32_t d = (key[r] >> shift) & mask;
+                    const uint32_t pos = off[w][d] + rank[r];
+                    dst[pos] = row[r];
+                    if (last) keys_out[lo + pos] = hi | key[r];
+                }
+            }
+            // off[] is rewritten only behind the next tile's first barrier, which every wave reaches
+            // after these reads
+        }
+        __syncthreads();                                // this pass' stores are visible to the whole workgroup
+        CS_STAMP();
+    }
+    // ---- cell heads
+    for (int i0 = tid; i0 < cn; i0 += HU * CS_THREADS) {
+        uint64_t ka[HU], kb[HU];
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            const int i = i0 + u * CS_THREADS;
+            const int j = i < cn ? i : i0;
+            ka[u] = keys_out[lo + j];
+            kb[u] = j > 0 ? keys_out[lo + j - 1] : ~ka[u];
+        }
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            const int i = i0 + u * CS_THREADS;
+            if (i < cn) head[lo + i] = ka[u] != kb[u] ? 1u : 0u;
+        }
+    }
+#ifdef PCH_CS_STAMPS
+    __syncthreads();
+    CS_STAMP();
+#endif
 }
 
 __global__ __launch_bounds__(DB_THREADS) void db_cells_k(const uint64_t* __restrict__ keys,
@@ -283,7 +503,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
     const int cnt = (int)(e - s);
     {
         const int sh = g.bx + g.by + g.bz;
-        if (sh < 64 && (int64_t)(cell_key[c] >> sh) == g.trash_chunk) {   // points of NaN/inf chunks
+        if (g.chunk_bad[sh < 64 ? (cell_key[c] >> sh) : 0]) {            // points of NaN/inf chunks
             for (uint32_t i = s + l; i < e; i += 64) core_s[i] = 0;
             if (l == 0) cell_ncore[c] = 0;
             return;
@@ -687,7 +907,7 @@ struct DbWs {
     uint32_t* meta;         // [0..5] aabb ordered keys, [6] status, [7] m, [8] nclusters
     uint64_t *k0, *k1, *cell_key;
     uint32_t *v0, *v1, *head, *cid, *cell_start, *cell_ncore, *flag, *radix_ws, *scan_ws;
-    float4*   pts;
+    float4   *pts, *xbuf;
     uint8_t*  core_s;
     float*    cell_box;
     int      *parent, *root, *comp_min, *cell_label;
@@ -707,6 +927,7 @@ static void db_plan(Arena& a, int64_t n, DbWs& w) {
     w.head = a.take<uint32_t>(nn + 8);
     w.cid = a.take<uint32_t>(nn);
     w.pts = a.take<float4>(nn);
+    w.xbuf = a.take<float4>(nn);                        // spare rows array of the chunk-local sort
     w.core_s = a.take<uint8_t>(nn);
     w.cell_key = a.take<uint64_t>(nn);
     w.cell_start = a.take<uint32_t>(nn + 8);
@@ -769,9 +990,6 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
 
     int64_t gstride = ceil_div(n, DB_THREADS * 8);
     if (gstride > 2048) gstride = 2048;
-    PCH_HIP_TRY(hipMemsetAsync(w.chunk_bad, 0, sizeof(uint32_t) * (size_t)(nchunks + 1), s));
-    PCH_LAUNCH("db_chunkbad", db_chunkbad_k, dim3((unsigned)gstride), dim3(DB_THREADS), 0, s, xyz, n,
-               chunk_size, w.chunk_bad);
     float box[6];
     if (aabb_host) {
         memcpy(box, aabb_host, sizeof(box));
@@ -799,17 +1017,18 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
     DbGrid g;
     g.ox = box[0]; g.oy = box[1]; g.oz = box[2];
     g.cell = eps / 1.7320508075688772 * (1.0 - 1.0 / 65536.0);
+    g.inv_cell = 1.0 / g.cell;
     g.eps2 = eps * eps;
     g.eps2_lo = nextafterf((float)(g.eps2 * (1.0 - 1.0 / 1048576.0)), -INFINITY);
     g.eps2_hi = nextafterf((float)(g.eps2 * (1.0 + 1.0 / 1048576.0)), INFINITY);
     if (!(g.eps2_hi < 3.0e38f)) { g.eps2_lo = -1.0f; g.eps2_hi = NAN; }    // absurd eps: exact path only
     g.chunk_size = chunk_size;
-    g.trash_chunk = nchunks;
+    g.chunk_bad = w.chunk_bad;
     g.min_samples = min_samples;
     double ext[3];
     int mc[3];
     for (int k = 0; k < 3; ++k) {
-        ext[k] = ((double)box[3 + k] - (double)box[k]) / g.cell;
+        ext[k] = ((double)box[3 + k] - (double)box[k]) * g.inv_cell;
         if (!(ext[k] < 2.0e9)) { set_error("cell grid too large (extent/eps too big)"); return PCH_ERR_RANGE; }
         mc[k] = (int)ext[k] + 1;                 // +1: slack for the rounding of the division
     }
@@ -817,7 +1036,8 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
     g.bx = bits_for((uint64_t)g.mx + 1);
     g.by = bits_for((uint64_t)g.my + 1);
     g.bz = bits_for((uint64_t)g.mz + 1);
-    const int nbits = g.bx + g.by + g.bz + bits_for((uint64_t)nchunks + 1);
+    const int cellbits = g.bx + g.by + g.bz;
+    const int nbits = cellbits + bits_for((uint64_t)nchunks);
     if (nbits > 64) {
         set_error("cell key needs %d bits (> 64): extent/eps too large for this chunking", nbits);
         return PCH_ERR_RANGE;
@@ -825,13 +1045,35 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
 
     const unsigned gn = (unsigned)ceil_div(n, DB_THREADS);
     PCH_HIP_TRY(hipMemsetAsync(w.meta + 6, 0, 4 * sizeof(uint32_t), s));
-    PCH_LAUNCH("db_keys", db_keys_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, n, g,
-               (const uint32_t*)w.chunk_bad, w.k0, w.v0, w.meta + 6);
-    PCH_TRY(radix_sort_pairs(w.k0, w.v0, w.k1, w.v1, n, nbits, w.radix_ws, s));
-    const bool in1 = radix_sort_result_buffer(nbits) == 1;
-    const uint64_t* ks = in1 ? w.k1 : w.k0;
-    const uint32_t* vs = in1 ? w.v1 : w.v0;
-    PCH_LAUNCH("db_gather", db_gather_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, ks, vs, n, w.pts, w.head);
+    const uint64_t* ks;
+    if (cellbits <= 32 && chunk_size <= CS_MAX_CHUNK) {
+        // chunk-local path: one workgroup per chunk builds keys, sorts and gathers
+        const int passes = cellbits <= 0 ? 0 : (cellbits + 7) / 8;
+        const int dbits = passes ? (cellbits + passes - 1) / passes : 1;
+        PCH_LAUNCH("db_chunksort", db_chunksort_k, dim3((unsigned)nchunks), dim3(CS_THREADS), 0, s, xyz, n, g,
+                   w.chunk_bad, w.xbuf, w.pts, w.k1, w.head, w.meta + 6, passes, dbits,
+                   (unsigned long long*)w.cell_box);
+#ifdef PCH_CS_STAMPS
+        {
+            unsigned long long t[8];
+            PCH_HIP_TRY(hipMemcpy(t, w.cell_box, sizeof(t), hipMemcpyDeviceToHost));
+            for (int q = 1; q <= passes + 2; ++q)
+                fprintf(stderr, "chunksort phase %d: %.2f us\n", q, (double)(t[q] - t[q - 1]) / 100.0);
+        }
+#endif
+        ks = w.k1;
+    } else {
+        PCH_HIP_TRY(hipMemsetAsync(w.chunk_bad, 0, sizeof(uint32_t) * (size_t)(nchunks + 1), s));
+        PCH_LAUNCH("db_chunkbad", db_chunkbad_k, dim3((unsigned)gstride), dim3(DB_THREADS), 0, s, xyz, n,
+                   chunk_size, w.chunk_bad);
+        PCH_LAUNCH("db_keys", db_keys_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, n, g,
+                   (const uint32_t*)w.chunk_bad, w.k0, w.v0, w.meta + 6);
+        PCH_TRY(radix_sort_pairs(w.k0, w.v0, w.k1, w.v1, n, nbits, w.radix_ws, s));
+        const bool in1 = radix_sort_result_buffer(nbits) == 1;
+        ks = in1 ? w.k1 : w.k0;
+        const uint32_t* vs = in1 ? w.v1 : w.v0;
+        PCH_LAUNCH("db_gather", db_gather_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, ks, vs, n, w.pts, w.head);
+    }
     PCH_TRY(scan_exclusive_u32(w.head, w.head, n, w.scan_ws, w.meta + 7, s));
     uint32_t st_m[2];
     PCH_HIP_TRY(hipMemcpyAsync(st_m, w.meta + 6, sizeof(st_m), hipMemcpyDeviceToHost, s));

@@ -278,163 +278,180 @@ static SideStream& side_stream() {
 }
 
 // =====================================================================================
-// B2/B3: keep = (z - cz) > thr, order preserving.  Two launches over the raw points:
-// count (both thresholds at once, so the <min_keep fallback needs no host round trip),
-// then scatter of the centred coordinates.
+// B2/B3: keep = (z - cz) > thr, order preserving, in ONE sweep over the z column: every
+// workgroup counts its tile, publishes the count and obtains its output offset by a decoupled
+// look-back over the tiles in front of it (status word = 2-bit flag + 32-bit value, one 64-bit
+// relaxed atomic), then writes the centred survivors and folds their bounding box into one of
+// 64 slot sets.  The sweep runs with the first threshold (offset); only if that keeps fewer than
+// min_keep points (utils/tower_extraction.py:87-89) a second sweep with the fallback threshold
+// overwrites the output - its workgroups return at once otherwise.
 // =====================================================================================
 constexpr int GF_THREADS = 256;
-constexpr int GF_ROUNDS  = 8;
-constexpr int GF_TILE    = GF_THREADS * GF_ROUNDS;   // 2048 points per workgroup
+constexpr int GF_ROUNDS  = 64;
+constexpr int GF_TILE    = GF_THREADS * GF_ROUNDS;   // 16 384 points per workgroup: few enough tiles for the look-back
+constexpr int GF_LOOK    = 4;                        // 64-tile windows fetched per look-back round trip
+constexpr int GF_SLOTS   = 64;
 
 struct GfState {
-    uint32_t total_a, total_b;             // kept with threshold A (offset) / B (fallback): scan totals
+    uint32_t total[2];                     // kept with threshold A (offset) / B (fallback)
     uint32_t use_b;
-    uint32_t aabb[6];                      // ordered-uint32 min xyz / max xyz
     uint32_t pad;
+    uint32_t slots[2][GF_SLOTS][6];        // per sweep: ~min xyz (complemented) / max xyz as ordered uint32,
+                                           // all folded with atomicMax so that 0 is the neutral start
 };
 
-__global__ __launch_bounds__(GF_THREADS) void gf_count_k(const float* __restrict__ zcol, int64_t n,
-                                                         const float* __restrict__ centroid,
-                                                         const float* __restrict__ scal,
-                                                         uint32_t* __restrict__ cnt_a,
-                                                         uint32_t* __restrict__ cnt_b) {
-    __shared__ uint32_t sa[GF_THREADS / 64], sb[GF_THREADS / 64];
-    const float cz = centroid[2];
-    const float thr_a = scal[1], thr_b = scal[2];
-    const int64_t base = (int64_t)blockIdx.x * GF_TILE;
-    uint32_t a = 0, b = 0;
-#pragma unroll
-    for (int r = 0; r < GF_ROUNDS; ++r) {
-        const int64_t i = base + r * GF_THREADS + threadIdx.x;
-        if (i < n) {
-            const float z = zcol[i] - cz;
-            a += (z > thr_a);
-            b += (z > thr_b);
-        }
-    }
-    a = wave_reduce_add(a);
-    b = wave_reduce_add(b);
-    if (lane_id() == 0) { sa[wave_id()] = a; sb[wave_id()] = b; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t ta = sa[0] + sa[1] + sa[2] + sa[3];
-        const uint32_t tb = sb[0] + sb[1] + sb[2] + sb[3];
-        cnt_a[blockIdx.x] = ta;
-        cnt_b[blockIdx.x] = tb;
-    }
-}
+constexpr uint64_t GF_FLAG_AGG = 1ull << 62, GF_FLAG_INCL = 2ull << 62;
 
-// picks the threshold (utils/tower_extraction.py:87-89) and publishes the scalars
-__global__ void gf_decide_k(GfState* __restrict__ st, long long min_keep,
-                            const float* __restrict__ centroid, float* __restrict__ scal,
-                            float* __restrict__ out_scalars, int64_t* __restrict__ out_count) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const bool use_b = (long long)st->total_a < min_keep;
-    st->use_b = use_b ? 1u : 0u;
-    const float thr = use_b ? scal[2] : scal[1];
-    scal[3] = thr;
-    out_scalars[0] = centroid[0];
-    out_scalars[1] = centroid[1];
-    out_scalars[2] = centroid[2];
-    out_scalars[3] = scal[0];
-    out_scalars[4] = thr;
-    out_scalars[5] = use_b ? 1.0f : 0.0f;
-    out_scalars[6] = (float)st->total_a;      // kept at the first threshold (exact below 2^24)
-    out_scalars[7] = 0.0f;
-    *out_count = (int64_t)(use_b ? st->total_b : st->total_a);
-    for (int a = 0; a < 3; ++a) { st->aabb[a] = 0xFFFFFFFFu; st->aabb[3 + a] = 0u; }
-}
-
-__global__ __launch_bounds__(GF_THREADS) void gf_scatter_k(
-    const float* __restrict__ raw, const float* __restrict__ zcol, int64_t n,
-    const float* __restrict__ centroid,
-    const float* __restrict__ scal, const uint32_t* __restrict__ off_a,
-    const uint32_t* __restrict__ off_b, GfState* __restrict__ st,
-    float* __restrict__ out_points, int32_t* __restrict__ out_index) {
-    __shared__ uint32_t wtot[GF_THREADS / 64];
-    const float cx = centroid[0], cy = centroid[1], cz = centroid[2];
-    const float thr = scal[3];
-    const uint32_t block_off = st->use_b ? off_b[blockIdx.x] : off_a[blockIdx.x];
-    const int w = wave_id(), l = lane_id();
-    const int64_t seg = (int64_t)blockIdx.x * GF_TILE + (int64_t)w * (64 * GF_ROUNDS);
-    float px[GF_ROUNDS], py[GF_ROUNDS], pz[GF_ROUNDS];
-    uint32_t pos[GF_ROUNDS];
-    uint32_t run = 0;
-    const uint64_t lt = lanemask_lt();
+// exclusive prefix of tile b (wave 0 of the workgroup, all 64 lanes); T = this tile's count
+__device__ __forceinline__ uint32_t gf_lookback(uint64_t* __restrict__ status, int64_t b, uint32_t T) {
+    const int l = lane_id();
+    if (b == 0) {
+        if (l == 0) __hip_atomic_store(&status[0], GF_FLAG_INCL | T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    if (l == 0) __hip_atomic_store(&status[b], GF_FLAG_AGG | T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0;
+    bool done = false;
+    for (int64_t j = b - 1; !done; j -= 64 * GF_LOOK) {  // windows [j-64k-63, j-64k]: lane l looks at tile j-64k-l
+        uint64_t v[GF_LOOK];
+        do {                                            // tiles in front were dispatched earlier: they publish
+            bool missing = false;
 #pragma unroll
-    for (int r = 0; r < GF_ROUNDS; ++r) {
-        const int64_t i = seg + r * 64 + l;
-        bool keep = false;
-        if (i < n) {
-            pz[r] = zcol[i] - cz;                 // points = raw_points - centroid (float32)
-            keep = pz[r] > thr;
-            if (keep) {                           // x,y are only fetched for survivors
-                px[r] = raw[3 * i + 0] - cx;
-                py[r] = raw[3 * i + 1] - cy;
+            for (int k = 0; k < GF_LOOK; ++k) {
+                const int64_t idx = j - 64 * k - l;
+                v[k] = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : GF_FLAG_INCL;         // in front of tile 0: prefix 0
+                missing |= (v[k] >> 62) == 0;
+            }
+            if (__ballot(missing) == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        } while (true);
+#pragma unroll
+        for (int k = 0; k < GF_LOOK; ++k) {
+            if (done) break;
+            const unsigned long long incl = __ballot((v[k] >> 62) == 2);
+            if (incl) {                                 // nearest tile with a full prefix ends the walk
+                const int first = (int)__builtin_ctzll(incl);
+                excl += wave_reduce_add(l <= first ? (uint32_t)v[k] : 0u);
+                done = true;
+            } else {
+                excl += wave_reduce_add((uint32_t)v[k]);
             }
         }
-        const uint64_t m = __ballot(keep);
-        pos[r] = keep ? run + (uint32_t)__popcll(m & lt) : 0xFFFFFFFFu;
+    }
+    if (l == 0) __hip_atomic_store(&status[b], GF_FLAG_INCL | (uint64_t)(excl + T), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+template <int WHICH>
+__global__ __launch_bounds__(GF_THREADS) void gf_compact_k(
+    const float* __restrict__ raw, const float* __restrict__ zcol, int64_t n,
+    const float* __restrict__ centroid, const float* __restrict__ scal, GfState* __restrict__ st,
+    uint64_t* __restrict__ status, float* __restrict__ out_points, int32_t* __restrict__ out_index) {
+    __shared__ uint32_t wtot[GF_THREADS / 64];
+    __shared__ uint32_t excl_sh;
+    __shared__ uint32_t box[GF_THREADS / 64][6];
+    __shared__ unsigned long long masks[GF_THREADS / 64][GF_ROUNDS];      // survivors of every 64-point round
+    if (WHICH == 1 && st->use_b == 0) return;
+    const float cx = centroid[0], cy = centroid[1], cz = centroid[2];
+    const float thr = scal[1 + WHICH];
+    const int w = wave_id(), l = lane_id();
+    const int64_t seg = (int64_t)blockIdx.x * GF_TILE + (int64_t)w * (64 * GF_ROUNDS);
+    // ---- sweep over the z column: survivor masks and the tile's count
+    uint32_t run = 0;
+#pragma unroll 8
+    for (int r = 0; r < GF_ROUNDS; ++r) {
+        const int64_t i = seg + r * 64 + l;
+        const float z = i < n ? zcol[i] : 0.0f;
+        const bool keep = i < n && (z - cz) > thr;       // points = raw_points - centroid (float32)
+        const unsigned long long m = __ballot(keep);
+        if (l == 0) masks[w][r] = m;
         run += (uint32_t)__popcll(m);
     }
     if (l == 0) wtot[w] = run;
     __syncthreads();
-    uint32_t woff = block_off;
-    for (int w2 = 0; w2 < w; ++w2) woff += wtot[w2];
-#pragma unroll
-    for (int r = 0; r < GF_ROUNDS; ++r) {
-        if (pos[r] != 0xFFFFFFFFu) {
-            const int64_t o = (int64_t)woff + pos[r];
-            out_points[3 * o + 0] = px[r];
-            out_points[3 * o + 1] = py[r];
-            out_points[3 * o + 2] = pz[r];
-            if (out_index) out_index[o] = (int32_t)(seg + r * 64 + l);
+    const uint32_t T = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    if (w == 0) {
+        const uint32_t e = gf_lookback(status, blockIdx.x, T);
+        if (l == 0) {
+            excl_sh = e;
+            if (blockIdx.x == gridDim.x - 1) st->total[WHICH] = e + T;
         }
     }
-}
-
-// bounding box of the kept points: grid-stride over the compacted output, one set of atomics per
-// workgroup
-__global__ __launch_bounds__(256) void gf_aabb_k(const float* __restrict__ pts, const int64_t* __restrict__ count,
-                                                 GfState* __restrict__ st) {
-    __shared__ uint32_t sm[4][6];
-    const int64_t total = 3 * (*count);
-    uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
-    // flat float index e = 3*i + axis; a thread's stride (gridDim*256*... ) is a multiple of 3 so
-    // every thread always sees the same axis
-    const int64_t stride = (int64_t)gridDim.x * 256 * 3;
-    for (int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 3; e0 < total; e0 += stride) {
-        const float x = pts[e0], y = pts[e0 + 1], z = pts[e0 + 2];
-        if (!(fabsf(x) < INFINITY && fabsf(y) < INFINITY && fabsf(z) < INFINITY)) continue;   // NaN/inf rows
-        const float v[3] = {x, y, z};
+    __syncthreads();
+    if (T == 0) return;                                       // workgroup-uniform
+    // ---- survivors: the row (one 12-byte load) is only fetched for them
+    struct Row3 { float x, y, z; };
+    uint32_t woff = excl_sh;
+    for (int w2 = 0; w2 < w; ++w2) woff += wtot[w2];
+    uint32_t lo[3] = {0u, 0u, 0u}, hi[3] = {0u, 0u, 0u};      // lo holds ~ordered(min)
+    const uint64_t lt = lanemask_lt();
+#pragma unroll 4
+    for (int r = 0; r < GF_ROUNDS; ++r) {
+        const unsigned long long m = masks[w][r];
+        if ((m >> l) & 1ull) {
+            const int64_t i = seg + r * 64 + l;
+            const Row3 q = reinterpret_cast<const Row3*>(raw)[i];
+            const float v[3] = {q.x - cx, q.y - cy, q.z - cz};
+            const int64_t o = (int64_t)woff + (uint32_t)__popcll(m & lt);
+            out_points[3 * o + 0] = v[0];
+            out_points[3 * o + 1] = v[1];
+            out_points[3 * o + 2] = v[2];
+            if (out_index) out_index[o] = (int32_t)i;
+            if (fabsf(v[0]) < INFINITY && fabsf(v[1]) < INFINITY && fabsf(v[2]) < INFINITY) {   // NaN/inf rows
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const uint32_t k = f32_ordered(v[a]);
-            lo[a] = k < lo[a] ? k : lo[a];
-            hi[a] = k > hi[a] ? k : hi[a];
+                for (int a = 0; a < 3; ++a) {
+                    const uint32_t k = f32_ordered(v[a]);
+                    lo[a] = ~k > lo[a] ? ~k : lo[a];
+                    hi[a] = k > hi[a] ? k : hi[a];
+                }
+            }
         }
+        woff += (uint32_t)__popcll(m);
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        lo[a] = wave_reduce_min(lo[a]);
+        lo[a] = wave_reduce_max(lo[a]);
         hi[a] = wave_reduce_max(hi[a]);
-        if (lane_id() == 0) { sm[wave_id()][a] = lo[a]; sm[wave_id()][3 + a] = hi[a]; }
+        if (l == 0) { box[w][a] = lo[a]; box[w][3 + a] = hi[a]; }
     }
     __syncthreads();
     if (threadIdx.x < 6) {
         const int a = threadIdx.x;
-        uint32_t v = sm[0][a];
-        for (int w = 1; w < 4; ++w) v = (a < 3) ? (sm[w][a] < v ? sm[w][a] : v) : (sm[w][a] > v ? sm[w][a] : v);
-        if (a < 3) { if (v != 0xFFFFFFFFu) atomicMin(&st->aabb[a], v); }
-        else       { if (v != 0u) atomicMax(&st->aabb[a], v); }
+        uint32_t v = box[0][a];
+        for (int w2 = 1; w2 < GF_THREADS / 64; ++w2) v = box[w2][a] > v ? box[w2][a] : v;
+        if (v) atomicMax(&st->slots[WHICH][blockIdx.x % GF_SLOTS][a], v);
     }
 }
 
-__global__ void gf_finalize_k(const GfState* __restrict__ st, float* __restrict__ out_aabb) {
-    if (threadIdx.x < 6 && blockIdx.x == 0 && out_aabb) {
-        const uint32_t k = st->aabb[threadIdx.x];
-        const bool empty = (threadIdx.x < 3) ? (k == 0xFFFFFFFFu) : (k == 0u);
-        out_aabb[threadIdx.x] = empty ? 0.0f : f32_unordered(k);
+// after the first sweep: does the fallback threshold apply (utils/tower_extraction.py:87-89)?
+__global__ void gf_decide_k(GfState* __restrict__ st, long long min_keep) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) st->use_b = ((long long)st->total[0] < min_keep) ? 1u : 0u;
+}
+
+// publishes the scalars, the count and the bounding box of the sweep that counts
+__global__ void gf_finalize_k(const GfState* __restrict__ st, const float* __restrict__ centroid,
+                              const float* __restrict__ scal, float* __restrict__ out_scalars,
+                              int64_t* __restrict__ out_count, float* __restrict__ out_aabb) {
+    if (blockIdx.x != 0) return;
+    const uint32_t use_b = st->use_b;
+    if (threadIdx.x == 0) {
+        out_scalars[0] = centroid[0];
+        out_scalars[1] = centroid[1];
+        out_scalars[2] = centroid[2];
+        out_scalars[3] = scal[0];
+        out_scalars[4] = scal[1 + use_b];
+        out_scalars[5] = use_b ? 1.0f : 0.0f;
+        out_scalars[6] = (float)st->total[0];     // kept at the first threshold (exact below 2^24)
+        out_scalars[7] = 0.0f;
+        *out_count = (int64_t)st->total[use_b];
+    }
+    if (threadIdx.x < 6 && out_aabb) {
+        const int a = threadIdx.x;
+        uint32_t v = 0;
+        for (int k = 0; k < GF_SLOTS; ++k) { const uint32_t u = st->slots[use_b][k][a]; v = u > v ? u : v; }
+        out_aabb[a] = v == 0u ? 0.0f : f32_unordered(a < 3 ? ~v : v);
     }
 }
 
@@ -444,7 +461,8 @@ struct GfWs {
     MsWs      ms;
     SelWs     sel;
     GfState*  st;
-    uint32_t *cnt_a, *cnt_b, *scan_ws;
+    uint64_t* status;            // [2][tiles] look-back words of the two sweeps
+    size_t    clear_bytes;       // st .. end of status: zeroed before the sweeps
 };
 static void gf_plan(Arena& a, int64_t n, GfWs& w) {
     const int64_t nb = ceil_div(n > 0 ? n : 1, GF_TILE);
@@ -452,10 +470,10 @@ static void gf_plan(Arena& a, int64_t n, GfWs& w) {
     ms_plan(a, n, w.ms);
     w.zcol = a.take<float>(n > 0 ? n : 1);
     sel_plan(a, w.sel);
+    const size_t st_off = a.off;
     w.st = a.take<GfState>(1);
-    w.cnt_a = a.take<uint32_t>(nb + 8);
-    w.cnt_b = a.take<uint32_t>(nb + 8);
-    w.scan_ws = a.take<uint32_t>(scan_ws_u32(nb));
+    w.status = a.take<uint64_t>(2 * nb);
+    w.clear_bytes = a.off - st_off;
 }
 
 }  // namespace pch
@@ -548,21 +566,14 @@ extern "C" int pch_ground_filter_f32(const float* raw, int64_t n, double pct, fl
         PCH_TRY(select_passes(w.zcol, n, 1, pct, w.sel, s));
     }
     PCH_TRY(select_lerp(n, w.centroid + 2, pct, offset, fallback_offset, w.sel, s));
-    PCH_HIP_TRY(hipMemsetAsync(w.st, 0, sizeof(GfState), s));
-    PCH_LAUNCH("gf_count", gf_count_k, dim3((unsigned)nb), dim3(GF_THREADS), 0, s, (const float*)w.zcol, n,
-               (const float*)w.centroid, (const float*)w.sel.scal, w.cnt_a, w.cnt_b);
-    PCH_TRY(scan_exclusive_u32(w.cnt_a, w.cnt_a, nb, w.scan_ws, &w.st->total_a, s));
-    PCH_TRY(scan_exclusive_u32(w.cnt_b, w.cnt_b, nb, w.scan_ws, &w.st->total_b, s));
-    PCH_LAUNCH("gf_decide", gf_decide_k, dim3(1), dim3(64), 0, s, w.st, (long long)min_keep,
-               (const float*)w.centroid, w.sel.scal, out_scalars, out_count);
-    PCH_LAUNCH("gf_scatter", gf_scatter_k, dim3((unsigned)nb), dim3(GF_THREADS), 0, s, raw,
-               (const float*)w.zcol, n,
-               (const float*)w.centroid, (const float*)w.sel.scal, (const uint32_t*)w.cnt_a,
-               (const uint32_t*)w.cnt_b, w.st, out_points, out_index);
-    if (out_aabb) {
-        PCH_LAUNCH("gf_aabb", gf_aabb_k, dim3(512), dim3(256), 0, s, (const float*)out_points,
-                   (const int64_t*)out_count, w.st);
-        PCH_LAUNCH("gf_finalize", gf_finalize_k, dim3(1), dim3(64), 0, s, (const GfState*)w.st, out_aabb);
-    }
+    PCH_HIP_TRY(hipMemsetAsync(w.st, 0, w.clear_bytes, s));
+    const dim3 grid((unsigned)nb), blk(GF_THREADS);
+    PCH_LAUNCH("gf_compact", gf_compact_k<0>, grid, blk, 0, s, raw, (const float*)w.zcol, n,
+               (const float*)w.centroid, (const float*)w.sel.scal, w.st, w.status, out_points, out_index);
+    PCH_LAUNCH("gf_decide", gf_decide_k, dim3(1), dim3(64), 0, s, w.st, (long long)min_keep);
+    PCH_LAUNCH("gf_compact_fb", gf_compact_k<1>, grid, blk, 0, s, raw, (const float*)w.zcol, n,
+               (const float*)w.centroid, (const float*)w.sel.scal, w.st, w.status + nb, out_points, out_index);
+    PCH_LAUNCH("gf_finalize", gf_finalize_k, dim3(1), dim3(64), 0, s, (const GfState*)w.st,
+               (const float*)w.centroid, (const float*)w.sel.scal, out_scalars, out_count, out_aabb);
     return PCH_OK;
 }

@@ -33,8 +33,9 @@ __global__ __launch_bounds__(SG_THREADS) void sg_perm_k(const uint32_t* __restri
     if (i < n) perm[i] = (int32_t)vals[i];
 }
 
-// bounding box per cluster: waves walk the label-sorted rows (1024 per wave); a wave almost
-// always sees a single label, reduces in registers and issues six ordered-uint atomics
+// bounding box per cluster: waves walk the rows in file order (1024 per wave, coalesced reads);
+// neighbouring rows mostly share a label, which a wave reduces in registers before it issues six
+// ordered-uint atomics
 __global__ __launch_bounds__(SG_THREADS) void sg_stats_init_k(uint32_t* __restrict__ acc, int32_t nclusters) {
     const int i = blockIdx.x * SG_THREADS + threadIdx.x;
     if (i < 6 * nclusters) acc[i] = (i % 6) < 3 ? 0xFFFFFFFFu : 0u;
@@ -53,34 +54,36 @@ __device__ __forceinline__ void sg_flush(uint32_t* __restrict__ acc, int cur, co
 }
 
 __global__ __launch_bounds__(SG_THREADS) void sg_stats_k(const float* __restrict__ xyz,
-                                                         const int32_t* __restrict__ perm,
-                                                         const uint64_t* __restrict__ keys, int64_t n,
+                                                         const int32_t* __restrict__ labels, int64_t n,
                                                          int32_t nclusters, uint32_t* __restrict__ acc) {
     const int64_t w = (int64_t)blockIdx.x * (SG_THREADS / 64) + wave_id();
     const int l = lane_id();
     int cur = -1;
     uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    struct Row3 { float x, y, z; };
+    int lab16[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                         // rows in file order: coalesced label reads
+        const int64_t j = w * 1024 + r * 64 + l;
+        const int v = j < n ? labels[j] : -1;
+        lab16[r] = (v >= 0 && v < nclusters) ? v : -1;
+    }
     for (int r = 0; r < 16; ++r) {
         const int64_t j = w * 1024 + r * 64 + l;
-        int lab = -1;
+        const int lab = lab16[r];
         uint32_t k[3] = {0, 0, 0};
-        if (j < n) {
-            const uint64_t key = keys[j];
-            if (key < (uint64_t)nclusters) {               // noise rows carry key == nclusters
-                lab = (int)key;
-                const int64_t p = perm[j];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) k[a] = f32_ordered(xyz[3 * p + a]);
-            }
+        if (lab >= 0) {
+            const Row3 q = reinterpret_cast<const Row3*>(xyz)[j];
+            k[0] = f32_ordered(q.x); k[1] = f32_ordered(q.y); k[2] = f32_ordered(q.z);
         }
-        // rows are sorted by label: handle the labels present in this round one at a time
+        // neighbouring rows mostly share a label: handle the labels present in this round one at a time
         unsigned long long todo = __ballot(lab >= 0);
         while (todo) {
             const int lead = (int)__builtin_ctzll(todo);
             const int L = __builtin_amdgcn_readlane(lab, lead);
             const unsigned long long same = __ballot(lab == L);
             todo &= ~same;
-            if (L != cur) {                                // a new label starts: flush the previous one
+            if (L != cur) {                                // another label: flush the one carried so far
                 sg_flush(acc, cur, lo, hi);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) { lo[a] = 0xFFFFFFFFu; hi[a] = 0u; }
@@ -96,6 +99,106 @@ __global__ __launch_bounds__(SG_THREADS) void sg_stats_k(const float* __restrict
         }
     }
     sg_flush(acc, cur, lo, hi);
+}
+
+// ---- one-pass counting sort for at most 255 clusters (bins 0..K-1, noise = bin K) ---------
+constexpr int SL_ROUNDS = 8;
+constexpr int SL_TILE   = SG_THREADS * SL_ROUNDS;          // 2048 labels per workgroup
+
+__device__ __forceinline__ uint32_t sl_bin(int32_t l, int32_t nclusters) {
+    return (l < 0 || l >= nclusters) ? (uint32_t)nclusters : (uint32_t)l;     // noise last
+}
+
+__global__ __launch_bounds__(SG_THREADS) void sl_hist_k(const int32_t* __restrict__ labels, int64_t n,
+                                                        int32_t nclusters, uint32_t* __restrict__ hist,
+                                                        int64_t nb) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SL_TILE;
+    int32_t v[SL_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SL_ROUNDS; ++r) {
+        const int64_t i = base + r * SG_THREADS + threadIdx.x;
+        v[r] = i < n ? labels[i] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < SL_ROUNDS; ++r) {
+        const int64_t i = base + r * SG_THREADS + threadIdx.x;
+        // rows of a wave mostly share a bin: one merged add for the first active lane's bin
+        const bool in = i < n;
+        const uint32_t b = sl_bin(v[r], nclusters);
+        const unsigned long long act = __ballot(in);
+        if (act) {
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)b, (int)__builtin_ctzll(act));
+            const unsigned long long same = __ballot(in && b == b0);
+            if (lane_id() == (int)__builtin_ctzll(act)) atomicAdd(&h[b0], (uint32_t)__popcll(same));
+            if (in && b != b0) atomicAdd(&h[b], 1u);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x <= nclusters) hist[(int64_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(SG_THREADS) void sl_scatter_k(const int32_t* __restrict__ labels, int64_t n,
+                                                           int32_t nclusters,
+                                                           const uint32_t* __restrict__ offs, int64_t nb,
+                                                           int32_t* __restrict__ perm) {
+    constexpr int WAVES = SG_THREADS / 64;
+    __shared__ uint32_t cnt[WAVES][256];
+    const int w = wave_id(), l = lane_id();
+    for (int j = threadIdx.x; j < WAVES * 256; j += SG_THREADS) (&cnt[0][0])[j] = 0;
+    __syncthreads();
+    const int64_t seg = (int64_t)blockIdx.x * SL_TILE + (int64_t)w * (64 * SL_ROUNDS);
+    uint32_t bin[SL_ROUNDS], rank[SL_ROUNDS];
+    const uint64_t lt = lanemask_lt();
+#pragma unroll
+    for (int r = 0; r < SL_ROUNDS; ++r) {
+        const int64_t i = seg + r * 64 + l;
+        bin[r] = sl_bin(i < n ? labels[i] : -1, nclusters);
+    }
+#pragma unroll
+    for (int r = 0; r < SL_ROUNDS; ++r) {
+        const bool valid = seg + r * 64 + l < n;
+        const uint32_t d = bin[r];
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t prior = cnt[w][d];
+        const uint32_t rk = (uint32_t)__popcll(peers & lt);
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rk == 0) cnt[w][d] = prior + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        rank[r] = prior + rk;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x <= nclusters) {
+        const int d = threadIdx.x;
+        uint32_t run = offs[(int64_t)d * nb + blockIdx.x];
+#pragma unroll
+        for (int w2 = 0; w2 < WAVES; ++w2) {
+            const uint32_t c = cnt[w2][d];
+            cnt[w2][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SL_ROUNDS; ++r) {
+        const int64_t i = seg + r * 64 + l;
+        if (i < n) perm[cnt[w][bin[r]] + rank[r]] = (int32_t)i;
+    }
+}
+
+// offsets[k] = start of bin k = scanned count of (bin k, tile 0); offsets[K] = start of the noise rows
+__global__ __launch_bounds__(SG_THREADS) void sl_offsets_k(const uint32_t* __restrict__ offs, int64_t nb,
+                                                           int32_t nclusters, int64_t* __restrict__ offsets) {
+    const int k = blockIdx.x * SG_THREADS + threadIdx.x;
+    if (k <= nclusters) offsets[k] = (int64_t)offs[(int64_t)k * nb];
 }
 
 __global__ __launch_bounds__(SG_THREADS) void sg_stats_out_k(const uint32_t* __restrict__ acc, int32_t nclusters,
@@ -115,15 +218,24 @@ __global__ __launch_bounds__(SG_THREADS) void sg_stats_out_k(const uint32_t* __r
 struct SgWs {
     uint64_t *k0, *k1;
     uint32_t *v0, *v1, *radix_ws, *acc;
+    uint32_t *table, *table_scan;      // one-pass path: [bins][tiles] counts + scan scratch
 };
 static void sg_plan(Arena& a, int64_t n, int32_t nclusters, SgWs& w) {
     const int64_t nn = n > 0 ? n : 1;
     w.acc = a.take<uint32_t>(6 * (size_t)(nclusters > 0 ? nclusters : 1));
-    w.k0 = a.take<uint64_t>(nn);
-    w.k1 = a.take<uint64_t>(nn);
-    w.v0 = a.take<uint32_t>(nn);
-    w.v1 = a.take<uint32_t>(nn);
-    w.radix_ws = a.take<uint32_t>(radix_ws_u32(nn));
+    if (nclusters < 256) {                                 // labels + noise fit one 8-bit digit
+        const int64_t table = ((int64_t)nclusters + 1) * ceil_div(nn, SL_TILE);
+        w.table = a.take<uint32_t>(table);
+        w.table_scan = a.take<uint32_t>(scan_ws_u32(table));
+        w.k0 = w.k1 = nullptr; w.v0 = w.v1 = w.radix_ws = nullptr;
+    } else {
+        w.table = w.table_scan = nullptr;
+        w.k0 = a.take<uint64_t>(nn);
+        w.k1 = a.take<uint64_t>(nn);
+        w.v0 = a.take<uint32_t>(nn);
+        w.v1 = a.take<uint32_t>(nn);
+        w.radix_ws = a.take<uint32_t>(radix_ws_u32(nn));
+    }
 }
 
 }  // namespace pch
@@ -156,20 +268,32 @@ extern "C" int pch_segment_by_label(const int32_t* labels, const float* xyz, int
     sg_plan(a, n, nclusters, w);
     if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
     const unsigned gn = (unsigned)ceil_div(n, SG_THREADS);
-    PCH_LAUNCH("seg_keys", sg_keys_k, dim3(gn), dim3(SG_THREADS), 0, s, labels, n, nclusters, w.k0, w.v0);
-    const int nbits = bits_for((uint64_t)nclusters + 1);
-    PCH_TRY(radix_sort_pairs(w.k0, w.v0, w.k1, w.v1, n, nbits, w.radix_ws, s));
-    const bool in1 = radix_sort_result_buffer(nbits) == 1;
-    const uint64_t* ks = in1 ? w.k1 : w.k0;
-    const uint32_t* vs = in1 ? w.v1 : w.v0;
-    PCH_LAUNCH("seg_perm", sg_perm_k, dim3(gn), dim3(SG_THREADS), 0, s, vs, n, out_perm);
-    PCH_LAUNCH("seg_offsets", sg_offsets_k, dim3((unsigned)ceil_div((int64_t)nclusters + 1, SG_THREADS)),
-               dim3(SG_THREADS), 0, s, ks, n, nclusters, out_offsets);
+    if (nclusters < 256) {
+        const int64_t nb = ceil_div(n, SL_TILE);
+        const int64_t table = ((int64_t)nclusters + 1) * nb;
+        PCH_LAUNCH("seg_hist", sl_hist_k, dim3((unsigned)nb), dim3(SG_THREADS), 0, s, labels, n, nclusters,
+                   w.table, nb);
+        PCH_TRY(scan_exclusive_u32(w.table, w.table, table, w.table_scan, nullptr, s));
+        PCH_LAUNCH("seg_scatter", sl_scatter_k, dim3((unsigned)nb), dim3(SG_THREADS), 0, s, labels, n, nclusters,
+                   (const uint32_t*)w.table, nb, out_perm);
+        PCH_LAUNCH("seg_offsets", sl_offsets_k, dim3((unsigned)ceil_div((int64_t)nclusters + 1, SG_THREADS)),
+                   dim3(SG_THREADS), 0, s, (const uint32_t*)w.table, nb, nclusters, out_offsets);
+    } else {
+        PCH_LAUNCH("seg_keys", sg_keys_k, dim3(gn), dim3(SG_THREADS), 0, s, labels, n, nclusters, w.k0, w.v0);
+        const int nbits = bits_for((uint64_t)nclusters + 1);
+        PCH_TRY(radix_sort_pairs(w.k0, w.v0, w.k1, w.v1, n, nbits, w.radix_ws, s));
+        const bool in1 = radix_sort_result_buffer(nbits) == 1;
+        const uint64_t* ks = in1 ? w.k1 : w.k0;
+        const uint32_t* vs = in1 ? w.v1 : w.v0;
+        PCH_LAUNCH("seg_perm", sg_perm_k, dim3(gn), dim3(SG_THREADS), 0, s, vs, n, out_perm);
+        PCH_LAUNCH("seg_offsets", sg_offsets_k, dim3((unsigned)ceil_div((int64_t)nclusters + 1, SG_THREADS)),
+                   dim3(SG_THREADS), 0, s, ks, n, nclusters, out_offsets);
+    }
     if (out_stats && nclusters > 0) {
         PCH_LAUNCH("seg_stats_init", sg_stats_init_k, dim3((unsigned)ceil_div(6 * (int64_t)nclusters, SG_THREADS)),
                    dim3(SG_THREADS), 0, s, w.acc, nclusters);
         PCH_LAUNCH("seg_stats", sg_stats_k, dim3((unsigned)ceil_div(n, 1024 * (SG_THREADS / 64))), dim3(SG_THREADS),
-                   0, s, xyz, (const int32_t*)out_perm, ks, n, nclusters, w.acc);
+                   0, s, xyz, labels, n, nclusters, w.acc);
         PCH_LAUNCH("seg_stats_out", sg_stats_out_k, dim3((unsigned)ceil_div(8 * (int64_t)nclusters, SG_THREADS)),
                    dim3(SG_THREADS), 0, s, (const uint32_t*)w.acc, nclusters, out_stats);
     }

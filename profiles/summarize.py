@@ -46,7 +46,7 @@ def pmc(d, counter):
 fetch, write = pmc(fetch_dir, "FETCH_SIZE"), pmc(write_dir, "WRITE_SIZE")
 names = {"ms_summary_k": "mean_summary", "ms_walk_k": "mean_walk", "ms_level2_k": "mean_level2",
          "db_core_k": "db_core", "db_union_k": "db_union", "db_border_k": "db_border",
-         "gf_count_k": "gf_count", "gf_scatter_k": "gf_scatter", "sel_hist_k<0>": "sel_hist0",
+         "gf_compact_k<0>": "gf_compact", "gf_compact_k<1>": "gf_compact_fb", "db_chunksort_k": "db_chunksort", "sel_hist_k<0>": "sel_hist0",
          "sel_hist_k<1>": "sel_hist1", "sel_hist_k<2>": "sel_hist2", "rs_scatter_k": "radix_scatter",
          "rs_hist_k": "radix_hist", "db_gather_k": "db_gather", "db_keys_k": "db_keys",
          "sg_stats_k": "seg_stats", "db_label_k": "db_label", "db_cellbox_k": "db_cellbox"}

@@ -310,11 +310,12 @@ def test_dbscan_border_tie_takes_smallest_cluster(cuda):
 
 
 # ------------------------------------------------------------------------------ stage D0
-def test_segment_by_label(cuda):
+@pytest.mark.parametrize("n,K", [(100000, 37), (100000, 255), (70001, 256), (50000, 1000), (3000, 1)])
+def test_segment_by_label(cuda, n, K):
     rng = np.random.default_rng(9)
-    n, K = 100000, 37
     labels = rng.integers(-1, K, n).astype(np.int32)
     labels[labels == 5] = -1                                        # an empty cluster
+    labels[1000:1800] = min(3, K - 1)                               # a run of one label (merged adds)
     xyz = rng.normal(0, 10, (n, 3)).astype(np.float32)
     perm, offs, stats = ops.segment_by_label(_dev(labels, cuda), _dev(xyz, cuda), K)
     perm, offs, stats = perm.cpu().numpy(), offs.cpu().numpy(), stats.cpu().numpy()
