@@ -163,6 +163,42 @@ int pch_segment_by_label(const int32_t* labels, const float* xyz, int64_t n,
                          int32_t nclusters, int32_t* out_perm, int64_t* out_offsets,
                          float* out_stats, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------- stages B + C + D0 in one call
+ * The body of extract_towers between "points are loaded" and the per-label loop
+ * (utils/tower_extraction.py:62-125): pch_ground_filter_f32, pch_dbscan_f32 on the kept points
+ * (cell grid sized from the filter's bounding box) and pch_segment_by_label, back to back on
+ * `stream` with one shared workspace.  Same results as the three calls.
+ * out_points  [n,3] float32, out_index [n] int32 (may be NULL): as pch_ground_filter_f32
+ * out_labels  [nf_cap] int32: labels of the kept points (first info->count entries)
+ * out_perm    [nf_cap] int32, out_offsets [k_cap+1] int64, out_stats [k_cap,8] float32 (may be
+ *             NULL): as pch_segment_by_label; pass out_perm = NULL to skip the grouping
+ * nf_cap      upper bound on the kept points the caller is prepared for (<= n); if the filter
+ *             keeps more: PCH_ERR_WORKSPACE, info->count says how many (retry with nf_cap >= it)
+ * k_cap       capacity of out_offsets / out_stats; more clusters: PCH_ERR_RANGE (labels and
+ *             info are valid, group with pch_segment_by_label)
+ * info_host   HOST struct, filled on return.  Synchronises (three times: kept count, cell count,
+ *             cluster count); the device outputs are complete once `stream` is.
+ */
+typedef struct PchTowerClusters {
+    float   centroid[3];      /* np.mean(raw.astype(f32), axis=0)            (:62-63) */
+    float   base;             /* np.percentile(points[:,2], pct)             (:82)    */
+    float   threshold;        /* base + offset, or base + fallback_offset    (:87-89) */
+    int32_t used_fallback;
+    int64_t count_at_offset;  /* points kept by the first threshold */
+    float   aabb[6];          /* min xyz, max xyz of the kept (centred) points */
+    int64_t count;            /* points kept */
+    int32_t nclusters;
+    int32_t reserved;
+} PchTowerClusters;
+size_t pch_tower_clusters_ws_bytes(int64_t n, int64_t nf_cap, int32_t k_cap);
+int pch_tower_clusters_f32(const float* raw, int64_t n, double pct, float offset,
+                           float fallback_offset, int64_t min_keep, double eps,
+                           int32_t min_samples, int64_t chunk_size,
+                           float* out_points, int32_t* out_index, int32_t* out_labels,
+                           int32_t* out_perm, int64_t* out_offsets, float* out_stats,
+                           int64_t nf_cap, int32_t k_cap, PchTowerClusters* info_host,
+                           void* ws, size_t ws_bytes, void* stream);
+
 /* --------------------------------------------------------- profiling helpers
  * Last-call timings recorded with hipEvents on the caller's stream when
  * pch_set_profiling(1): fills up to `cap` (name, total ms, launch count) triples for the

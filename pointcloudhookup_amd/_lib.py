@@ -47,10 +47,22 @@ _SIGS = {
     "pch_dbscan_f32": (C.c_int, [_vp, _i64, _f64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pch_segment_by_label_ws_bytes": (_sz, [_i64, _i32]),
     "pch_segment_by_label": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pch_tower_clusters_ws_bytes": (_sz, [_i64, _i64, _i32]),
+    "pch_tower_clusters_f32": (C.c_int, [_vp, _i64, _f64, _f32, _f32, _i64, _f64, _i32, _i64, _vp, _vp, _vp,
+                                         _vp, _vp, _vp, _i64, _i32, _vp, _vp, _sz, _vp]),
     "pch_set_profiling": (None, [C.c_int]),
     "pch_set_profiling_filter": (None, [C.c_char_p]),
     "pch_get_profile": (C.c_int, [C.c_int, _vp, _vp, _vp]),
 }
+
+
+
+class TowerClustersInfo(C.Structure):
+    """PchTowerClusters (include/pch_hip.h)."""
+    _fields_ = [("centroid", C.c_float * 3), ("base", C.c_float), ("threshold", C.c_float),
+                ("used_fallback", C.c_int32), ("count_at_offset", C.c_int64), ("aabb", C.c_float * 6),
+                ("count", C.c_int64), ("nclusters", C.c_int32), ("reserved", C.c_int32)]
+
 
 _lib = None
 

@@ -1,0 +1,98 @@
+// Stages B + C + D0 behind one entry point: what utils/tower_extraction.py:62-125 does between
+// "points are loaded" and "loop over the cluster labels".  Nothing new is computed here - the
+// three stage entry points are called back to back on the caller's stream, sharing one
+// workspace (a stage's scratch is dead once the next stage starts) and reading the two host-side
+// sizes the next launch needs (points kept, clusters found) without a trip through the host
+// language in between.
+#include "pch_common.h"
+
+#include <cstring>
+
+namespace pch {
+
+// device-side mirror of the filter's host results: scalars[8], aabb[6], pad[2], count (int64)
+struct DevInfo {
+    float   scalars[8];
+    float   aabb[6];
+    float   pad[2];
+    int64_t count;
+    int32_t nclusters;
+    int32_t pad2;
+};
+
+static size_t max3(size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+
+}  // namespace pch
+
+using namespace pch;
+
+extern "C" size_t pch_tower_clusters_ws_bytes(int64_t n, int64_t nf_cap, int32_t k_cap) {
+    if (n < 0 || nf_cap < 0 || k_cap < 0) return 0;
+    Arena a;
+    a.take<DevInfo>(1);
+    return a.off + max3(pch_ground_filter_ws_bytes(n), pch_dbscan_ws_bytes(nf_cap),
+                        pch_segment_by_label_ws_bytes(nf_cap, k_cap));
+}
+
+extern "C" int pch_tower_clusters_f32(const float* raw, int64_t n, double pct, float offset,
+                                      float fallback_offset, int64_t min_keep, double eps,
+                                      int32_t min_samples, int64_t chunk_size, float* out_points,
+                                      int32_t* out_index, int32_t* out_labels, int32_t* out_perm,
+                                      int64_t* out_offsets, float* out_stats, int64_t nf_cap,
+                                      int32_t k_cap, PchTowerClusters* info_host, void* ws,
+                                      size_t ws_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    PCH_REQUIRE(info_host != nullptr, "info_host is null");
+    memset(info_host, 0, sizeof(*info_host));
+    PCH_REQUIRE(ws != nullptr && nf_cap >= 0 && k_cap >= 0, "bad argument");
+    Arena a(ws, ws_bytes);
+    DevInfo* dev = a.take<DevInfo>(1);
+    if (a.overflow || ws_bytes < pch_tower_clusters_ws_bytes(n, nf_cap, k_cap)) {
+        set_error("workspace too small: need %zu bytes", pch_tower_clusters_ws_bytes(n, nf_cap, k_cap));
+        return PCH_ERR_WORKSPACE;
+    }
+    void* sub = static_cast<char*>(ws) + a.off;
+    const size_t sub_bytes = ws_bytes - a.off;
+
+    // ---- stage B
+    PCH_TRY(pch_ground_filter_f32(raw, n, pct, offset, fallback_offset, min_keep, out_points, out_index,
+                                  dev->scalars, &dev->count, dev->aabb, sub, sub_bytes, stream));
+    DevInfo h;
+    PCH_HIP_TRY(hipMemcpyAsync(&h, dev, sizeof(DevInfo), hipMemcpyDeviceToHost, s));
+    PCH_HIP_TRY(hipStreamSynchronize(s));
+    memcpy(info_host->centroid, h.scalars, 3 * sizeof(float));
+    info_host->base = h.scalars[3];
+    info_host->threshold = h.scalars[4];
+    info_host->used_fallback = h.scalars[5] != 0.0f;
+    info_host->count_at_offset = (int64_t)h.scalars[6];
+    memcpy(info_host->aabb, h.aabb, sizeof(h.aabb));
+    info_host->count = h.count;
+    const int64_t nf = h.count;
+    if (nf > nf_cap) {
+        set_error("the filter kept %lld points, more than nf_cap = %lld", (long long)nf, (long long)nf_cap);
+        return PCH_ERR_WORKSPACE;
+    }
+    if (nf == 0) {                                       // nothing above the ground: no clusters
+        if (out_offsets) PCH_HIP_TRY(hipMemsetAsync(out_offsets, 0, sizeof(int64_t), s));
+        return PCH_OK;
+    }
+    // ---- stage C (the filter's scratch is dead; its outputs are the caller's buffers)
+    PCH_REQUIRE(out_labels != nullptr, "out_labels is null");
+    PCH_TRY(pch_dbscan_f32(out_points, nf, eps, min_samples, chunk_size, h.aabb, out_labels, nullptr,
+                           &dev->nclusters, sub, sub_bytes, stream));
+    int32_t k = 0;
+    PCH_HIP_TRY(hipMemcpyAsync(&k, &dev->nclusters, sizeof(k), hipMemcpyDeviceToHost, s));
+    PCH_HIP_TRY(hipStreamSynchronize(s));
+    info_host->nclusters = k;
+    // ---- stage D0
+    if (out_perm && out_offsets) {
+        if (k > k_cap) {
+            set_error("%d clusters found, more than k_cap = %d (labels are valid; group them with "
+                      "pch_segment_by_label)", (int)k, (int)k_cap);
+            return PCH_ERR_RANGE;
+        }
+        PCH_TRY(pch_segment_by_label(out_labels, out_points, nf, k, out_perm, out_offsets, out_stats, sub,
+                                     sub_bytes, stream));
+    }
+    return PCH_OK;
+}

@@ -189,15 +189,15 @@ def ground_filter(raw, pct=25.0, offset=3.0, fallback_offset=1.0, min_keep=1000,
     with torch.cuda.device(dev):
         out_points = torch.empty((n, 3), dtype=torch.float32, device=dev)
         out_index = torch.empty((n,), dtype=torch.int32, device=dev) if want_index else None
-        scal = torch.zeros((16,), dtype=torch.float32, device=dev)     # [0:8] scalars, [8:14] aabb
-        cnt = torch.zeros((1,), dtype=torch.int64, device=dev)
+        scal = torch.zeros((18,), dtype=torch.float32, device=dev)     # [0:8] scalars, [8:14] aabb, [16:18] count (int64)
         nb = L.pch_ground_filter_ws_bytes(n)
         ws = _workspace(nb, dev)
         _lib.check(L.pch_ground_filter_f32(_ptr(raw), n, float(pct), float(offset), float(fallback_offset),
                                            int(min_keep), _ptr(out_points), _ptr(out_index), _ptr(scal),
-                                           _ptr(cnt), scal.data_ptr() + 32, _ptr(ws), ws.numel(), _stream()))
+                                           scal.data_ptr() + 64, scal.data_ptr() + 32, _ptr(ws), ws.numel(),
+                                           _stream()))
         host = scal.cpu().numpy()           # one D2H copy, synchronises the stream
-        nf = int(cnt.item())
+        nf = int(host[16:18].view("<i8")[0])
     return dict(points=out_points[:nf], index=None if out_index is None else out_index[:nf],
                 centroid=host[0:3].copy(), base=host[3], threshold=host[4],
                 used_fallback=bool(host[5] != 0.0), count_at_offset=int(host[6]),
@@ -227,6 +227,58 @@ def dbscan(xyz, eps=8.0, min_samples=80, chunk_size=50000, aabb=None, want_core=
                                     _ptr(core), _ptr(ncl), _ptr(ws), ws.numel(), _stream()))
         k = int(ncl.item())
     return labels, core, k
+
+
+# ---------------------------------------------------------------------- stages B + C + D0
+_nf_hint = {}          # device index -> points kept by the previous call (sizes the next workspace)
+
+
+def tower_clusters(raw, eps=8.0, min_samples=80, chunk_size=50000, pct=25.0, offset=3.0,
+                   fallback_offset=1.0, min_keep=1000, want_index=False, segment=True, k_cap=65536):
+    """ground_filter + dbscan + segment_by_label behind one library call
+    (pch_tower_clusters_f32): the host language is not visited between the stages.
+    Returns (ground dict as ops.ground_filter, labels int32 [n_f], nclusters,
+    perm | None, offsets | None, stats | None)."""
+    import ctypes as C
+    import numpy as np
+    L = _lib.lib()
+    raw = _need_cuda(raw, torch.float32, "raw").reshape(-1, 3)
+    n = raw.shape[0]
+    dev = raw.device
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    hint = _nf_hint.get(key)
+    caps = [n] if hint is None else [min(n, max(int(hint * 1.25) + 1024, 1 << 16)), n]
+    with torch.cuda.device(dev):
+        out_points = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        out_index = torch.empty((n,), dtype=torch.int32, device=dev) if want_index else None
+        info = _lib.TowerClustersInfo()
+        for nf_cap in caps:
+            labels = torch.empty((nf_cap,), dtype=torch.int32, device=dev)
+            perm = torch.empty((nf_cap,), dtype=torch.int32, device=dev) if segment else None
+            offsets = torch.zeros((k_cap + 1,), dtype=torch.int64, device=dev) if segment else None
+            stats = torch.empty((k_cap, 8), dtype=torch.float32, device=dev) if segment else None
+            ws = _workspace(L.pch_tower_clusters_ws_bytes(n, nf_cap, k_cap), dev)
+            rc = L.pch_tower_clusters_f32(_ptr(raw), n, float(pct), float(offset), float(fallback_offset),
+                                          int(min_keep), float(eps), int(min_samples), int(chunk_size),
+                                          _ptr(out_points), _ptr(out_index), _ptr(labels), _ptr(perm),
+                                          _ptr(offsets), _ptr(stats), nf_cap, k_cap, C.addressof(info),
+                                          _ptr(ws), ws.numel(), _stream())
+            if rc == -2 and info.count > nf_cap and nf_cap < n:
+                continue                                   # kept more than the hint allowed for: once more, sized n
+            break
+        nf, k = int(info.count), int(info.nclusters)
+        if rc == -4 and segment and k > k_cap:             # more clusters than k_cap: group separately
+            perm, offsets, stats = segment_by_label(labels[:nf], out_points[:nf], k)
+            rc = 0
+        _lib.check(rc)
+    _nf_hint[key] = nf
+    ground = dict(points=out_points[:nf], index=None if out_index is None else out_index[:nf],
+                  centroid=np.array(info.centroid, dtype=np.float32), base=np.float32(info.base),
+                  threshold=np.float32(info.threshold), used_fallback=bool(info.used_fallback),
+                  count_at_offset=int(info.count_at_offset), aabb=np.array(info.aabb, dtype=np.float32), count=nf)
+    if not segment:
+        return ground, labels[:nf], k, None, None, None
+    return ground, labels[:nf], k, perm[:nf], offsets[:k + 1], stats[:k]
 
 
 # ---------------------------------------------------------------------------- stage D0

@@ -23,18 +23,11 @@ def cluster_points(raw, eps=8.0, min_points=80, chunk_size=REF_CHUNK, pct=25.0, 
     Returns dict: ground (ops.ground_filter result), labels int32 [N_f] (device), nclusters,
     perm / offsets / stats (ops.segment_by_label) when ``segment``.
     """
-    gf = ops.ground_filter(raw, pct, offset, fallback_offset, min_keep, want_index=want_index)
-    pts = gf["points"]
-    if gf["count"] == 0:
-        dev = raw.device
-        return dict(ground=gf, labels=torch.empty((0,), dtype=torch.int32, device=dev), nclusters=0,
-                    perm=torch.empty((0,), dtype=torch.int32, device=dev),
-                    offsets=torch.zeros((1,), dtype=torch.int64, device=dev),
-                    stats=torch.zeros((0, 8), dtype=torch.float32, device=dev))
-    labels, _, k = ops.dbscan(pts, eps, min_points, chunk_size, aabb=gf["aabb"])
+    gf, labels, k, perm, offsets, stats = ops.tower_clusters(
+        raw, eps, min_points, chunk_size, pct, offset, fallback_offset, min_keep,
+        want_index=want_index, segment=segment)
     out = dict(ground=gf, labels=labels, nclusters=k)
     if segment:
-        perm, offsets, stats = ops.segment_by_label(labels, pts, k)
         out.update(perm=perm, offsets=offsets, stats=stats)
     return out
 

@@ -188,3 +188,36 @@ def test_config3_100m_properties(cuda):
     assert torch.equal(lo, hi)
     stats = cl["stats"]
     assert float((stats[:, 3:6] - stats[:, 0:3]).max()) < 200.0
+
+
+def test_tower_clusters_equals_the_three_stage_calls(cuda):
+    """pch_tower_clusters_f32 (one library call) against ground_filter + dbscan +
+    segment_by_label called one by one: every output identical, also when the kept-points
+    hint is too small (second attempt) and when there are more clusters than k_cap."""
+    raw = synth.corridor_torch(2_000_000, seed=synth.SEED0 + 7, kind="corridor", offset=True, device=cuda,
+                               towers=6, dtype=torch.float32)
+    gf = ops.ground_filter(raw, want_index=True)
+    labels, _, k = ops.dbscan(gf["points"], 8.0, 80, 50000, aabb=gf["aabb"])
+    perm, offs, stats = ops.segment_by_label(labels, gf["points"], k)
+    assert k >= 2
+
+    def check(res):
+        g2, l2, k2, p2, o2, s2 = res
+        assert k2 == k and g2["count"] == gf["count"]
+        for name in ("centroid", "aabb"):
+            np.testing.assert_array_equal(np.asarray(g2[name]), np.asarray(gf[name]))
+        assert g2["base"] == gf["base"] and g2["threshold"] == gf["threshold"]
+        assert g2["used_fallback"] == gf["used_fallback"] and g2["count_at_offset"] == gf["count_at_offset"]
+        assert torch.equal(g2["points"], gf["points"]) and torch.equal(g2["index"], gf["index"])
+        assert torch.equal(l2, labels) and torch.equal(p2, perm) and torch.equal(o2, offs)
+        assert torch.equal(s2, stats)
+
+    key = torch.device(cuda).index or 0
+    ops._nf_hint.pop(key, None)
+    check(ops.tower_clusters(raw, want_index=True))                 # first call: sized for n
+    check(ops.tower_clusters(raw, want_index=True))                 # sized from the hint
+    ops._nf_hint[key] = 1000                                        # hint far too small: retried with n
+    check(ops.tower_clusters(raw, want_index=True))
+    check(ops.tower_clusters(raw, want_index=True, k_cap=1))        # more clusters than k_cap
+    g, l, kk, p, o, s = ops.tower_clusters(raw, segment=False)
+    assert p is None and kk == k and torch.equal(l, labels)
