@@ -33,15 +33,22 @@ __device__ __forceinline__ uint32_t sel_key(float v) {
 
 // adds 1 to h[bin] for every active lane; lanes of a wave that share a bin are merged into one
 // LDS atomic (z values of a flat corridor fall into a handful of bins)
+template <int ROUNDS>
 __device__ __forceinline__ void sel_hist_add(uint32_t* h, bool active, uint32_t bin) {
-    const unsigned long long todo = __ballot(active);
-    if (!todo) return;
-    // one merged atomic for the most likely bin (the first active lane's), plain atomics for the rest
-    const int leader = (int)__builtin_ctzll(todo);
-    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
-    const unsigned long long same = __ballot(active && bin == b0);
-    if (lane_id() == leader) atomicAdd(&h[b0], (uint32_t)__popcll(same));
-    if (active && bin != b0) atomicAdd(&h[bin], 1u);
+    // up to ROUNDS rounds of 'merge every lane that shares the first pending lane's bin into one
+    // LDS atomic' while many lanes are pending, plain atomics for the rest
+    bool pending = active;
+#pragma unroll
+    for (int round = 0; round < ROUNDS; ++round) {
+        const unsigned long long todo = __ballot(pending);
+        if (__popcll(todo) < 8) break;
+        const int leader = (int)__builtin_ctzll(todo);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
+        const unsigned long long same = __ballot(pending && bin == b0);
+        if (lane_id() == leader) atomicAdd(&h[b0], (uint32_t)__popcll(same));
+        pending = pending && bin != b0;
+    }
+    if (pending) atomicAdd(&h[bin], 1u);
 }
 
 template <int PASS>
@@ -56,12 +63,12 @@ __global__ __launch_bounds__(256) void sel_hist_k(const float* __restrict__ base
     auto take = [&](bool in, float v) {
         const uint32_t k = sel_key(v);
         if (PASS == 0) {
-            sel_hist_add(h, in, k >> 20);
+            sel_hist_add<3>(h, in, k >> 20);                  // z of a flat corridor: a handful of bins
             nans += (in && v != v);
         } else if (PASS == 1) {
-            sel_hist_add(h, in && (k >> 20) == prefix, (k >> 8) & 0xFFFu);
+            sel_hist_add<1>(h, in && (k >> 20) == prefix, (k >> 8) & 0xFFFu);
         } else {
-            sel_hist_add(h, in && (k >> 8) == prefix, k & 0xFFu);
+            sel_hist_add<1>(h, in && (k >> 8) == prefix, k & 0xFFu);
         }
     };
     // a workgroup takes tiles of 4096 values; on a contiguous, 16-byte aligned column every thread

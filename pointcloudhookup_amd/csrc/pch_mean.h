@@ -5,11 +5,12 @@
 namespace pch {
 
 struct MsHdr;
+struct MsRec;
 struct MsWs {
     int*       stats;            // [3][4]: level-2 batches, -, exactly added blocks, descents
-    MsHdr     *hdr, *hdr2;
-    long long *rows, *rows2;
-    uint32_t*  fix;              // [3][nb][24] sparse-tie adjustments (adj0 | adj1 << 16)
+    MsRec*     rec;              // [3][nb] level-1 records (three 128-byte lines per column and block)
+    MsHdr*     hdr2;
+    long long* rows2;
 };
 void ms_plan(Arena& a, int64_t n, MsWs& w);
 // centroid[3] = np.mean(xyz, axis=0) (float32).  zcol (optional, n floats) receives a copy of

@@ -27,7 +27,6 @@ namespace pch {
 constexpr int MSB       = 1024;    // points per summary block (one wave, 16 per lane)
 constexpr int MS_PER    = 16;
 constexpr int MS_CAND   = 24;
-constexpr int MS_ROW    = MS_CAND + 1;      // level-1 row: S[24], A0
 constexpr int MS_ROW2   = 3 * MS_CAND;      // level-2 row: N0[24], N1[24] (net per incoming parity), A[24]
 constexpr int MS_WAVES  = 4;
 constexpr uint32_t MS_NONFINITE = 1u, MS_ALLZERO = 2u;
@@ -36,10 +35,22 @@ constexpr int MS_FIX_MAX  = 8;      // ... holding at most this many tie element
 
 struct MsHdr { int emax; uint32_t tie; uint32_t flags; uint32_t pad; };
 
-// Table layout: candidate-major planes [column][slot][block], so that lanes that walk consecutive
-// blocks at (mostly) the same candidate read consecutive words.
-// level 1: slots 0..23 = S_j, slot 24 = A0 (MS_ROW planes); fix: 24 planes of uint32
-// level 2: slots 0..23 = N0_j, 24..47 = N1_j, 48..71 = A_j (MS_ROW2 planes)
+// level-1 record of one (column, block): three 128-byte lines, assembled in LDS and written by one
+// store instruction (whole lines: no read-modify-write in HBM), read by the lane that owns the
+// block in ms_level2_k / ms_walk_k
+struct alignas(128) MsRec {
+    MsHdr     h;
+    long long A0;                        // sum ceil|a / ulp(2^(emax+1))|
+    long long S[MS_CAND];                // S[j] = sum_i rne(a_i / 2^j ulps)
+    uint32_t  fix[MS_CAND];              // sparse-tie adjustments (adj0 & 0xFFFF) | adj1 << 16
+    uint32_t  pad[18];
+};
+static_assert(sizeof(MsRec) == 384 && offsetof(MsRec, A0) == 16 && offsetof(MsRec, S) == 24 &&
+              offsetof(MsRec, fix) == 24 + 8 * MS_CAND, "three cache lines per record; ms_level2_k reads it by word offsets");
+
+// Level-2 table layout: candidate-major planes [column][slot][row], so that lanes that walk
+// consecutive rows at (mostly) the same candidate read consecutive words:
+// slots 0..23 = N0_j, 24..47 = N1_j, 48..71 = A_j (MS_ROW2 planes)
 __host__ __device__ __forceinline__ int64_t ms_at(int c, int slot, int64_t blk, int64_t nblk, int planes) {
     return ((int64_t)c * planes + slot) * nblk + blk;
 }
@@ -54,16 +65,11 @@ __device__ __forceinline__ uint32_t ms_tie_bit(float x) {
 }
 
 __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __restrict__ xyz, int64_t n,
-                                                             int64_t nb, MsHdr* __restrict__ hdr,
-                                                             long long* __restrict__ rows,
-                                                             uint32_t* __restrict__ fix,
-                                                             float* __restrict__ zcol, int xcd_remap) {
+                                                             int64_t nb, MsRec* __restrict__ recs,
+                                                             float* __restrict__ zcol) {
     __shared__ __attribute__((aligned(16))) float lds[MS_WAVES][MSB * 3];
-    // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of blocks so
-    // that the partial-line table writes of neighbouring blocks meet in ONE L2
-    int64_t wg = blockIdx.x;
-    if (xcd_remap) wg = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int64_t blk = wg * MS_WAVES + wave_id();
+    __shared__ MsRec stage[MS_WAVES];                    // a record is assembled here, stored as whole lines
+    const int64_t blk = (int64_t)blockIdx.x * MS_WAVES + wave_id();
     if (blk >= nb) return;
     const int l = lane_id();
     const int64_t p0 = blk * MSB;
@@ -202,22 +208,25 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
             t[i] += __shfl_xor(t[i], 2, 64);
             t[i] += __shfl_xor(t[i], 1, 64);
         }
-        const int64_t row = (int64_t)c * nb + blk;
+        MsRec* rec = &stage[wave_id()];
         if ((l & 7) == 0) {
             const int j0 = (b5 ? 12 : 0) + (b4 ? 6 : 0) + (b3 ? 3 : 0);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) rows[ms_at(c, j0 + i, blk, nb, MS_ROW)] = t[i];
+            for (int i = 0; i < 3; ++i) rec->S[j0 + i] = t[i];
         }
-        if (l < MS_CAND) fix[ms_at(c, l, blk, nb, MS_CAND)] = myfix;
+        if (l < MS_CAND) rec->fix[l] = myfix;
+        if (l < 18) rec->pad[l] = 0;
         if (l == 0) {
-            rows[ms_at(c, MS_CAND, blk, nb, MS_ROW)] = A0w;
-            MsHdr h;
-            h.emax = emax;
-            h.tie = tie;
-            h.flags = (nonfinite ? MS_NONFINITE : 0u) | (mx == 0 ? MS_ALLZERO : 0u);
-            h.pad = 0;
-            hdr[row] = h;
+            rec->A0 = A0w;
+            rec->h.emax = emax;
+            rec->h.tie = tie;
+            rec->h.flags = (nonfinite ? MS_NONFINITE : 0u) | (mx == 0 ? MS_ALLZERO : 0u);
+            rec->h.pad = 0;
         }
+        __builtin_amdgcn_wave_barrier();
+        if (l < 24)                                            // 24 x 16 bytes: three full lines
+            reinterpret_cast<uint4*>(recs + (int64_t)c * nb + blk)[l] = reinterpret_cast<const uint4*>(rec)[l];
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -335,21 +344,48 @@ __device__ __forceinline__ uint32_t ms_block_exact(const float* __restrict__ xyz
 // increments are summed when no child depends on the incoming parity and composed IN ORDER
 // ((f then g)(p) = f(p) + g((p + f(p)) & 1)) when one does.  A child contributes nothing to
 // candidates 24 or more binades above its own largest element.
-__global__ __launch_bounds__(256) void ms_level2_k(const MsHdr* __restrict__ hdr,
-                                                   const long long* __restrict__ rows,
-                                                   const uint32_t* __restrict__ fix, int64_t nb,
+constexpr int MS_L2_PITCH = sizeof(MsRec) / 4 + 1;       // words per child in LDS (+1: bank spreading)
+
+__global__ __launch_bounds__(256) void ms_level2_k(const MsRec* __restrict__ recs, int64_t nb,
                                                    int64_t nb2, MsHdr* __restrict__ hdr2,
                                                    long long* __restrict__ rows2) {
-    const int64_t w = (int64_t)blockIdx.x * 4 + wave_id();
-    if (w >= 3 * nb2) return;
+    // one workgroup per (column, row): the 64 child records are contiguous (24 KiB), copied to LDS
+    // with coalesced 16-byte loads; lane l of every wave then reads the record of child l, and
+    // each of the four waves composes six of the 24 candidates
+    __shared__ uint32_t sh[64 * MS_L2_PITCH];
+    __shared__ uint32_t tie_sh;
+    const int64_t w = blockIdx.x;
     const int c = (int)(w / nb2);
     const int64_t g = w % nb2;
     const int l = lane_id();
     const int64_t bb = g * 64 + l;
     const bool valid = bb < nb;
+    {
+        const int nchild = (int)((nb - g * 64) < 64 ? (nb - g * 64) : 64);
+        const uint4* src = reinterpret_cast<const uint4*>(recs + (int64_t)c * nb + g * 64);
+        constexpr int VPR = sizeof(MsRec) / 16;            // 16-byte pieces per record
+        uint4 q[VPR / 4];
+#pragma unroll
+        for (int it = 0; it < VPR / 4; ++it) {
+            const int v = it * 256 + (int)threadIdx.x;
+            if (v < nchild * VPR) q[it] = src[v];
+        }
+#pragma unroll
+        for (int it = 0; it < VPR / 4; ++it) {
+            const int v = it * 256 + (int)threadIdx.x;
+            if (v < nchild * VPR) {
+                uint32_t* d = sh + (v / VPR) * MS_L2_PITCH + (v % VPR) * 4;
+                d[0] = q[it].x; d[1] = q[it].y; d[2] = q[it].z; d[3] = q[it].w;
+            }
+        }
+        if (threadIdx.x == 0) tie_sh = 0;
+        __syncthreads();
+    }
+    const uint32_t* rec = sh + l * MS_L2_PITCH;           // words: hdr 0..3, A0 4..5, S[j] 6+2j, fix[j] 54+j
+    auto rec64 = [&](int word) { return (long long)(((unsigned long long)rec[word + 1] << 32) | rec[word]); };
     MsHdr h;
     h.emax = -200; h.tie = 0; h.flags = MS_ALLZERO; h.pad = 0;
-    if (valid) h = hdr[(int64_t)c * nb + bb];
+    if (valid) { h.emax = (int)rec[0]; h.tie = rec[1]; h.flags = rec[2]; }
     const bool zero = (h.flags & MS_ALLZERO) != 0;
     const int emax2 = wave_reduce_max(zero ? -200 : h.emax);
     const uint32_t nonfinite = __ballot((h.flags & MS_NONFINITE) != 0) ? MS_NONFINITE : 0u;
@@ -357,15 +393,14 @@ __global__ __launch_bounds__(256) void ms_level2_k(const MsHdr* __restrict__ hdr
     uint32_t tie2 = 0;
     const int shift = emax2 - h.emax;                      // >= 0 for non-zero children
     const bool live = valid && !zero && !(h.flags & MS_NONFINITE);
-    const int64_t cb = valid ? bb : 0;
-    const long long A0 = live ? rows[ms_at(c, MS_CAND, cb, nb, MS_ROW)] : 0;
-    for (int j2 = 0; j2 < MS_CAND; ++j2) {
+    const long long A0 = live ? rec64(4) : 0;
+    for (int j2 = wave_id() * (MS_CAND / 4); j2 < (wave_id() + 1) * (MS_CAND / 4); ++j2) {
         const int j = j2 + shift;
         long long n0 = 0, n1 = 0, A = 0;
         bool tie = false;
         if (live && j < MS_CAND) {
-            const long long S = rows[ms_at(c, j, cb, nb, MS_ROW)];
-            const uint32_t f = fix[ms_at(c, j, cb, nb, MS_CAND)];
+            const long long S = rec64(6 + 2 * j);
+            const uint32_t f = rec[6 + 2 * MS_CAND + j];
             n0 = S + (long long)(short)(f & 0xFFFFu);
             n1 = S + (long long)(short)(f >> 16);
             A = (A0 >> j) + MSB;                           // >= sum |d_i| of the child at this binade
@@ -387,10 +422,12 @@ __global__ __launch_bounds__(256) void ms_level2_k(const MsHdr* __restrict__ hdr
             rows2[ms_at(c, 2 * MS_CAND + j2, g, nb2, MS_ROW2)] = A;
         }
     }
-    if (l == 0) {
+    if (l == 0 && tie2) atomicOr(&tie_sh, tie2);
+    __syncthreads();
+    if (threadIdx.x == 0) {
         MsHdr o;
         o.emax = allzero ? 0 : emax2;
-        o.tie = tie2;
+        o.tie = tie_sh;
         o.flags = nonfinite | (allzero ? MS_ALLZERO : 0u);
         o.pad = 0;
         hdr2[(int64_t)c * nb2 + g] = o;
@@ -398,7 +435,7 @@ __global__ __launch_bounds__(256) void ms_level2_k(const MsHdr* __restrict__ hdr
 }
 
 struct MsTables {
-    const MsHdr* hdr; const long long* rows; const uint32_t* fix; int64_t nb;   // level 1
+    const MsRec* rec; int64_t nb;                                               // level 1
     const MsHdr* hdr2; const long long* rows2; int64_t nb2;                     // level 2
 };
 
@@ -466,16 +503,17 @@ __device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ x
         const bool valid = l >= done && l < count;
         MsHdr h;
         h.emax = 0; h.tie = 0; h.flags = MS_ALLZERO; h.pad = 0;
-        if (valid) h = T.hdr[(int64_t)c * T.nb + bb];
+        const MsRec* rec = T.rec + (int64_t)c * T.nb + (valid ? bb : first);
+        if (valid) h = rec->h;
         int j;
         const int cls = ms_classify(h, valid, s_inf, s_norm, E, j);
         MsEntry en;
         en.n0 = en.n1 = en.lo = en.hi = 0;
         if (cls == 1) {
-            const long long S = T.rows[ms_at(c, j, bb, T.nb, MS_ROW)];
-            const uint32_t f = T.fix[ms_at(c, j, bb, T.nb, MS_CAND)];
+            const long long S = rec->S[j];
+            const uint32_t f = rec->fix[j];
             en = ms_entry(S + (long long)(short)(f & 0xFFFFu), S + (long long)(short)(f >> 16),
-                          (T.rows[ms_at(c, MS_CAND, bb, T.nb, MS_ROW)] >> j) + MSB, s_neg);
+                          (rec->A0 >> j) + MSB, s_neg);
         }
         int start = done;                               // first unresolved lane
         long long m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);   // mantissa entering `start`
@@ -589,9 +627,7 @@ void ms_plan(Arena& a, int64_t n, MsWs& w) {
     const int64_t nb = ceil_div(n > 0 ? n : 1, MSB);
     const int64_t nb2 = ceil_div(nb, 64);
     w.stats = a.take<int>(16);
-    w.hdr = a.take<MsHdr>(3 * nb);
-    w.rows = a.take<long long>(3 * nb * MS_ROW);
-    w.fix = a.take<uint32_t>(3 * nb * MS_CAND);
+    w.rec = a.take<MsRec>(3 * nb);
     w.hdr2 = a.take<MsHdr>(3 * nb2);
     w.rows2 = a.take<long long>(3 * nb2 * MS_ROW2);
 }
@@ -601,16 +637,14 @@ int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zco
     const int64_t nb = n > 0 ? ceil_div(n, MSB) : 0;
     const int64_t nb2 = ceil_div(nb, 64);
     if (n > 0) {
-        const int xcd_remap = 1;
-        const int64_t nwg = ceil_div(nb, MS_WAVES);
-        PCH_LAUNCH("mean_summary", ms_summary_k, dim3((unsigned)(xcd_remap ? (nwg + 7) / 8 * 8 : nwg)), dim3(64 * MS_WAVES),
-                   0, s, xyz, n, nb, w.hdr, w.rows, w.fix, zcol, xcd_remap);
+        PCH_LAUNCH("mean_summary", ms_summary_k, dim3((unsigned)ceil_div(nb, MS_WAVES)), dim3(64 * MS_WAVES),
+                   0, s, xyz, n, nb, w.rec, zcol);
         if (ev_zcol) PCH_HIP_TRY(hipEventRecord(ev_zcol, s));
-        PCH_LAUNCH("mean_level2", ms_level2_k, dim3((unsigned)ceil_div(3 * nb2, 4)), dim3(256), 0, s,
-                   (const MsHdr*)w.hdr, (const long long*)w.rows, (const uint32_t*)w.fix, nb, nb2, w.hdr2, w.rows2);
+        PCH_LAUNCH("mean_level2", ms_level2_k, dim3((unsigned)(3 * nb2)), dim3(256), 0, s,
+                   (const MsRec*)w.rec, nb, nb2, w.hdr2, w.rows2);
     }
     MsTables T;
-    T.hdr = w.hdr; T.rows = w.rows; T.fix = w.fix; T.nb = nb;
+    T.rec = w.rec; T.nb = nb;
     T.hdr2 = w.hdr2; T.rows2 = w.rows2; T.nb2 = nb2;
     PCH_LAUNCH("mean_walk", ms_walk_k, dim3(3), dim3(64), 0, s, xyz, n, T, out, w.stats);
     return PCH_OK;
