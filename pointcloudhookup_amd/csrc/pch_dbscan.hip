@@ -630,33 +630,133 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
 }
 
 // ---- per-cell box of the core points, union-find init ----------------------------------
-__global__ __launch_bounds__(DB_THREADS) void db_cellbox_k(const float4* __restrict__ pts,
-                                                           const uint32_t* __restrict__ cell_start,
-                                                           const uint8_t* __restrict__ core_s, int m,
+// ---- per-cell statistics of the core points: bounding box and smallest original row ----------
+// Points-parallel (a dense tower cell holds thousands of points - one wave per cell would leave a
+// long tail): a wave walks 1024 consecutive sorted points, 64 per round.  Inside a round the
+// values are combined by a segmented scan over the lanes (the points are sorted by cell, so a
+// cell is a run of lanes); a run that ends inside the round is folded into the cell's accumulator
+// with atomics, the run that reaches lane 63 is carried into the next round.  Accumulators hold
+// ordered uint32 keys folded with atomicMax (minima as the complement), so 0 = nothing yet.
+constexpr int DB_CS_ROUNDS = 16;
+
+__device__ __forceinline__ void db_cellstats_flush(uint32_t* __restrict__ acc, uint32_t c, const uint32_t (&v)[7]) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+        if (v[k]) atomicMax(&acc[8 * (int64_t)c + k], v[k]);
+}
+
+__global__ __launch_bounds__(DB_THREADS) void db_cellstats_k(const float4* __restrict__ pts,
+                                                             const uint32_t* __restrict__ cid,
+                                                             const uint8_t* __restrict__ core_s, int64_t n,
+                                                             uint32_t* __restrict__ acc) {
+    const int64_t base = ((int64_t)blockIdx.x * DB_WAVES + wave_id()) * (64 * DB_CS_ROUNDS);
+    if (base >= n) return;
+    const int l = lane_id();
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t carry_c = NONE;                                   // cell of the run that reached lane 63 ...
+    uint32_t carry[7] = {0, 0, 0, 0, 0, 0, 0};                 // ... its values so far (wave-uniform) ...
+    uint32_t mine[7] = {0, 0, 0, 0, 0, 0, 0};                  // ... plus whole rounds of it, still per lane
+    auto fold_mine = [&]() {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const uint32_t t = wave_reduce_max(mine[k]);
+            carry[k] = t > carry[k] ? t : carry[k];
+            mine[k] = 0;
+        }
+    };
+    for (int r0 = 0; r0 < DB_CS_ROUNDS; r0 += 4) {
+    if (base + r0 * 64 >= n) break;
+    uint32_t c4[4], core4[4];
+    float4 p4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                              // four rounds of loads in flight
+        const int64_t i = base + (r0 + u) * 64 + l;
+        const bool in = i < n;
+        c4[u] = in ? cid[i] : NONE - 1u;                       // past the end: a run of its own
+        core4[u] = in ? core_s[i] : 0u;
+        p4[u] = pts[in ? i : base];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + (r0 + u) * 64 + l;
+        const bool in = i < n;
+        const uint32_t c = c4[u];
+        uint32_t v[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (core4[u]) {
+            const float4 p = p4[u];
+            const uint32_t kx = f32_ordered(p.x), ky = f32_ordered(p.y), kz = f32_ordered(p.z);
+            v[0] = ~kx; v[1] = ~ky; v[2] = ~kz; v[3] = kx; v[4] = ky; v[5] = kz;
+            v[6] = ~__float_as_uint(p.w);                      // original row (< 2^31)
+        }
+        if (__ballot(c != carry_c) == 0) {                     // the whole round belongs to the carried cell
+#pragma unroll
+            for (int k = 0; k < 7; ++k) mine[k] = v[k] > mine[k] ? v[k] : mine[k];
+            continue;
+        }
+        if (carry_c != NONE) fold_mine();
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {                     // segmented inclusive max-scan
+            const uint32_t cu = __shfl_up(c, o, 64);
+            const bool same = l >= o && cu == c;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const uint32_t t = __shfl_up(v[k], o, 64);
+                if (same) v[k] = t > v[k] ? t : v[k];
+            }
+        }
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c, 0);
+        if (carry_c != NONE) {
+            if (carry_c == c0) {                               // the carried run continues: its end lane needs the carry
+                if (c == c0) {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) v[k] = carry[k] > v[k] ? carry[k] : v[k];
+                }
+            } else if (l == 0) {
+                db_cellstats_flush(acc, carry_c, carry);
+            }
+        }
+        const uint32_t cn = __shfl_down(c, 1, 64);
+        const bool run_end = l == 63 || cn != c;
+        if (run_end && l != 63 && in) db_cellstats_flush(acc, c, v);
+        carry_c = (uint32_t)__builtin_amdgcn_readlane((int)c, 63);
+        if (carry_c == NONE - 1u) carry_c = NONE;              // lane 63 is past the end: nothing to carry
+#pragma unroll
+        for (int k = 0; k < 7; ++k) carry[k] = (uint32_t)__builtin_amdgcn_readlane((int)v[k], 63);
+    }
+    }
+    if (carry_c != NONE) {
+        fold_mine();
+        if (l == 0) db_cellstats_flush(acc, carry_c, carry);
+    }
+}
+
+// accumulators -> bounding box floats (no core point: +inf / -inf) and smallest core row; also
+// resets the union-find forest
+__global__ __launch_bounds__(DB_THREADS) void db_cellfin_k(const uint32_t* __restrict__ acc, int m,
                                                            float* __restrict__ cell_box,
+                                                           int* __restrict__ cell_min,
                                                            int* __restrict__ parent,
                                                            int* __restrict__ comp_min) {
-    const int c = blockIdx.x * DB_WAVES + wave_id();
+    const int c = blockIdx.x * DB_THREADS + threadIdx.x;
     if (c >= m) return;
-    const int l = lane_id();
-    const uint32_t s = cell_start[c], e = cell_start[c + 1];
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = s + l; i < e; i += 64) {
-        if (core_s[i]) {
-            const float4 p = pts[i];
-            lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
-            lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
-            lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
-        }
+    uint32_t a[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) a[k] = acc[8 * (int64_t)c + k];
+    float box[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        box[k] = INFINITY;
+        box[3 + k] = -INFINITY;
+        if (a[k] != 0u) box[k] = f32_unordered(~a[k]);
+        if (a[3 + k] != 0u) box[3 + k] = f32_unordered(a[3 + k]);
     }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { lo[a] = wave_reduce_min(lo[a]); hi[a] = wave_reduce_max(hi[a]); }
-    if (l == 0) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { cell_box[6 * (int64_t)c + a] = lo[a]; cell_box[6 * (int64_t)c + 3 + a] = hi[a]; }
-        parent[c] = c;
-        comp_min[c] = INT_BIG;
-    }
+    for (int k = 0; k < 6; ++k) cell_box[6 * (int64_t)c + k] = box[k];
+    int mn = INT_BIG;
+    if (a[6] != 0u) mn = (int)(~a[6]);
+    cell_min[c] = mn;
+    parent[c] = c;
+    comp_min[c] = INT_BIG;
 }
 
 // ---- union-find over cells (hook larger root under smaller; lock free) ------------------
@@ -796,27 +896,17 @@ __global__ __launch_bounds__(DB_THREADS) void db_flatten_k(int* __restrict__ par
 }
 
 // root of every core cell + smallest original row among the component's core points
-__global__ __launch_bounds__(DB_THREADS) void db_compmin_k(const float4* __restrict__ pts,
-                                                           const uint32_t* __restrict__ cell_start,
-                                                           const uint8_t* __restrict__ core_s,
+__global__ __launch_bounds__(DB_THREADS) void db_compmin_k(const int* __restrict__ cell_min,
                                                            const uint32_t* __restrict__ cell_ncore, int m,
                                                            int* __restrict__ parent,
                                                            int* __restrict__ root,
                                                            int* __restrict__ comp_min) {
-    const int c = blockIdx.x * DB_WAVES + wave_id();
+    const int c = blockIdx.x * DB_THREADS + threadIdx.x;
     if (c >= m) return;
-    const int l = lane_id();
-    if (cell_ncore[c] == 0) { if (l == 0) root[c] = -1; return; }
-    const uint32_t s = cell_start[c], e = cell_start[c + 1];
-    int mn = INT_BIG;
-    for (uint32_t i = s + l; i < e; i += 64)
-        if (core_s[i]) { const int o = (int)__float_as_uint(pts[i].w); mn = o < mn ? o : mn; }
-    mn = wave_reduce_min(mn);
-    if (l == 0) {
-        const int r = uf_find(parent, c);
-        root[c] = r;
-        atomicMin(&comp_min[r], mn);
-    }
+    if (cell_ncore[c] == 0) { root[c] = -1; return; }
+    const int r = uf_find(parent, c);
+    root[c] = r;
+    atomicMin(&comp_min[r], cell_min[c]);
 }
 
 __global__ __launch_bounds__(DB_THREADS) void db_mark_k(const int* __restrict__ root,
@@ -910,6 +1000,8 @@ struct DbWs {
     float4   *pts, *xbuf;
     uint8_t*  core_s;
     float*    cell_box;
+    uint32_t* cell_acc;     // [cells][8] ordered-key accumulators of db_cellstats_k
+    int*      cell_min;     // smallest original row among a cell's core points
     int      *parent, *root, *comp_min, *cell_label;
     int2*     rowtab;
     int64_t   rowtab_cells;
@@ -933,6 +1025,8 @@ static void db_plan(Arena& a, int64_t n, DbWs& w) {
     w.cell_start = a.take<uint32_t>(nn + 8);
     w.cell_ncore = a.take<uint32_t>(nn);
     w.cell_box = a.take<float>(6 * nn);
+    w.cell_acc = a.take<uint32_t>(8 * nn);
+    w.cell_min = a.take<int>(nn);
     w.parent = a.take<int>(nn);
     w.root = a.take<int>(nn);
     w.comp_min = a.take<int>(nn);
@@ -1094,8 +1188,12 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
     }
     PCH_LAUNCH("db_core", db_core_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
                (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, w.core_s, w.cell_ncore);
-    PCH_LAUNCH("db_cellbox", db_cellbox_k, dim3(gc), dim3(DB_THREADS), 0, s, (const float4*)w.pts,
-               (const uint32_t*)w.cell_start, (const uint8_t*)w.core_s, m, w.cell_box, w.parent, w.comp_min);
+    PCH_HIP_TRY(hipMemsetAsync(w.cell_acc, 0, sizeof(uint32_t) * 8 * (size_t)m, s));
+    PCH_LAUNCH("db_cellstats", db_cellstats_k, dim3((unsigned)ceil_div(n, (int64_t)DB_WAVES * 64 * DB_CS_ROUNDS)),
+               dim3(DB_THREADS), 0, s, (const float4*)w.pts, (const uint32_t*)w.cid, (const uint8_t*)w.core_s, n,
+               w.cell_acc);
+    PCH_LAUNCH("db_cellfin", db_cellfin_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
+               (const uint32_t*)w.cell_acc, m, w.cell_box, w.cell_min, w.parent, w.comp_min);
     PCH_LAUNCH("db_union0", db_union_k<0>, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
                (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, (const uint8_t*)w.core_s,
                (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, w.parent);
@@ -1106,9 +1204,8 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
                (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, w.parent);
     PCH_LAUNCH("db_flatten", db_flatten_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
                w.parent, m);
-    PCH_LAUNCH("db_compmin", db_compmin_k, dim3(gc), dim3(DB_THREADS), 0, s, (const float4*)w.pts,
-               (const uint32_t*)w.cell_start, (const uint8_t*)w.core_s, (const uint32_t*)w.cell_ncore, m,
-               w.parent, w.root, w.comp_min);
+    PCH_LAUNCH("db_compmin", db_compmin_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
+               (const int*)w.cell_min, (const uint32_t*)w.cell_ncore, m, w.parent, w.root, w.comp_min);
     PCH_HIP_TRY(hipMemsetAsync(w.flag, 0, sizeof(uint32_t) * (size_t)n, s));
     PCH_LAUNCH("db_mark", db_mark_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
                (const int*)w.root, (const int*)w.comp_min, m, w.flag);
