@@ -794,9 +794,8 @@ __device__ __forceinline__ void uf_union(int* __restrict__ parent, int a, int b)
 // cells B > A whose core boxes are within eps and whose root differs from A's survive.
 // Phase 2 (wave-wide per survivor): look for one core pair within eps (lanes over B's points,
 // scalar loop over A's points, leave at the first hit), then unite.
-// ROUND 0 only looks at the (up to 3) face-adjacent cells with a larger index: for dense data
-// they connect at the first tile and leave almost nothing but root comparisons for ROUND 1.
-template <int ROUND>
+// db_union_face_k has looked at the (up to 3) face-adjacent cells with a larger index before: for
+// dense data they connect at the first tile and leave almost nothing but root comparisons here.
 __global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4* __restrict__ pts,
                                                          const uint32_t* __restrict__ cell_start,
                                                          const uint64_t* __restrict__ cell_key, int m,
@@ -816,23 +815,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4*
     const uint64_t keyA = cell_key[A];
     db_rows(g, cell_key, m, keyA, rs, rowtab, A);
     int total;
-    if (ROUND == 0) {
-        // the three face neighbours with a larger key: +x is the next cell in sorted order, +y / +z
-        // sit in the runs (dy,dz) = (1,0) / (0,1) (rows 1 and 3 of DB_ROW_DY/DZ)
-        if (l < 3) {
-            int B = -1;
-            if (l == 0) {
-                if (A + 1 < m && cell_key[A + 1] == keyA + 1ull) B = A + 1;
-            } else {
-                const int r = l == 1 ? 1 : 3;
-                const uint64_t want = keyA + (l == 1 ? (1ull << g.bx) : (1ull << (g.bx + g.by)));
-                for (int k = rs->ca[r]; k < rs->cb[r]; ++k)
-                    if (cell_key[k] == want) B = k;
-            }
-            cd[l] = B;
-        }
-        total = 3;
-    } else {
+    {
         // flatten the <= 25 runs of <= 5 cells into one candidate list (prefix over the run lengths)
         int len = 0;
         if (l < DB_ROWS) { len = rs->cb[l] - rs->ca[l]; len = len < 0 ? 0 : len; }
@@ -862,7 +845,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4*
             const int src = (int)__builtin_ctzll(todo);
             todo &= todo - 1;
             const int Bs = __builtin_amdgcn_readlane(B, src);
-            if (ROUND == 1) {                              // united meanwhile through another cell?
+            {                                              // united meanwhile through another cell?
                 int same = 0;
                 if (l == 0) same = uf_find(parent, A) == uf_find(parent, Bs);
                 if (__builtin_amdgcn_readfirstlane(same)) continue;
@@ -884,6 +867,112 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4*
             }
             if (connected && l == 0) uf_union(parent, A, Bs);
         }
+    }
+}
+
+// ROUND 0 as its own kernel: the (up to) three face neighbours with a larger key are examined side
+// by side, 21 lanes each, so that the chain of dependent loads (neighbour lookup, roots, first
+// points) is walked once per cell instead of once per neighbour.  Adjacent dense cells connect at
+// the first point pair; a pair that is still undecided after DB_FACE_TRIES points of A is handed
+// to the full-wave search of the general round.
+constexpr int DB_FACE_TRIES = 8;
+
+__global__ __launch_bounds__(DB_THREADS) void db_union_face_k(DbGrid g, const float4* __restrict__ pts,
+                                                              const uint32_t* __restrict__ cell_start,
+                                                              const uint64_t* __restrict__ cell_key, int m,
+                                                              const int2* __restrict__ rowtab,
+                                                              const uint8_t* __restrict__ core_s,
+                                                              const uint32_t* __restrict__ cell_ncore,
+                                                              const float* __restrict__ cell_box,
+                                                              int* __restrict__ parent) {
+    __shared__ RowSet rows[DB_WAVES];
+    const int A = blockIdx.x * DB_WAVES + wave_id();
+    if (A >= m) return;
+    const uint32_t ncoreA = cell_ncore[A];
+    if (ncoreA == 0) return;
+    const int l = lane_id();
+    const int grp = l / 21, gl = l - 21 * grp;             // lane 63: group 3, idle
+    const unsigned long long gmask = grp < 3 ? (0x1FFFFFull << (21 * grp)) : 0ull;
+    RowSet* rs = &rows[wave_id()];
+    const uint64_t keyA = cell_key[A];
+    db_rows(g, cell_key, m, keyA, rs, rowtab, A);
+    // +x is the next cell in sorted order, +y / +z sit in the runs (dy,dz) = (1,0) / (0,1)
+    // (rows 1 and 3 of DB_ROW_DY/DZ)
+    int B = -1;
+    {
+        bool found = false;
+        int k = -1;
+        if (grp == 0) {
+            k = A + 1;
+            found = gl == 0 && k < m && cell_key[k] == keyA + 1ull;
+        } else if (grp < 3) {
+            const int r = grp == 1 ? 1 : 3;
+            const uint64_t want = keyA + (grp == 1 ? (1ull << g.bx) : (1ull << (g.bx + g.by)));
+            k = rs->ca[r] + gl;
+            found = k < rs->cb[r] && cell_key[k] == want;
+        }
+        const unsigned long long fm = __ballot(found) & gmask;
+        if (fm) B = __shfl(k, (int)__builtin_ctzll(fm), 64);
+    }
+    const uint32_t as = cell_start[A], ae = cell_start[A + 1];
+    const bool a_dense = ncoreA == (ae - as);
+    uint32_t bs = 0, be = 0;
+    bool b_dense = false, pend = false;
+    float boxB[6] = {0, 0, 0, 0, 0, 0};
+    if (B > A) {
+        const uint32_t nB = cell_ncore[B];
+        bs = cell_start[B];
+        be = cell_start[B + 1];
+        b_dense = nB == (be - bs);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) boxB[a] = cell_box[6 * (int64_t)B + a];
+        pend = nB != 0 && !(db_boxbox_d2(cell_box + 6 * (int64_t)A, boxB) > g.eps2);
+        // plain (possibly stale) loads first: equal parents were in one set at some time, and sets only merge
+        if (pend) pend = parent[A] != parent[B];
+    }
+    if (gl != 0) pend = false;                             // one lane per group looks the roots up
+    if (pend) pend = uf_find(parent, A) != uf_find(parent, B);
+    pend = __shfl((int)pend, grp < 3 ? 21 * grp : 0, 64) != 0 && grp < 3;
+    bool connected = false;
+    uint32_t ia = as;
+    for (int tries = 0; ia < ae && tries < DB_FACE_TRIES; ++ia) {
+        if (__ballot(pend) == 0) break;
+        if (!a_dense && !core_s[ia]) continue;
+        ++tries;
+        const float4 pa = pts[ia];
+        bool near = pend && !(db_box_d2(pa, boxB) > g.eps2);
+        const uint32_t maxlen = wave_reduce_max(near ? be - bs : 0u);
+        for (uint32_t j0 = 0; j0 < maxlen; j0 += 21) {
+            const uint32_t j = bs + j0 + gl;
+            bool hit = false;
+            if (near && j < be && (b_dense || core_s[j])) hit = db_within2(pa, pts[j], g);
+            if (__ballot(hit) & gmask) { connected = true; pend = false; near = false; }
+            if (__ballot(near) == 0) break;
+        }
+    }
+    if (connected && gl == 0) uf_union(parent, A, B);
+    // undecided pairs (rare): the full-wave search, one pair after the other
+    unsigned long long todo = __ballot(pend && gl == 0);
+    while (todo) {
+        const int src = (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int Bs = __shfl(B, src, 64);
+        const uint32_t bs2 = cell_start[Bs], be2 = cell_start[Bs + 1];
+        const bool b_dense2 = cell_ncore[Bs] == (be2 - bs2);
+        const float* boxB2 = cell_box + 6 * (int64_t)Bs;
+        bool conn = false;
+        for (uint32_t i2 = ia; i2 < ae && !conn; ++i2) {
+            if (!a_dense && !core_s[i2]) continue;
+            const float4 pa = pts[i2];
+            if (db_box_d2(pa, boxB2) > g.eps2) continue;
+            for (uint32_t j0 = bs2; j0 < be2; j0 += 64) {
+                const uint32_t j = j0 + l;
+                bool hit = false;
+                if (j < be2 && (b_dense2 || core_s[j])) hit = db_within2(pa, pts[j], g);
+                if (__ballot(hit)) { conn = true; break; }
+            }
+        }
+        if (conn && l == 0) uf_union(parent, A, Bs);
     }
 }
 
@@ -1194,12 +1283,12 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
                w.cell_acc);
     PCH_LAUNCH("db_cellfin", db_cellfin_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
                (const uint32_t*)w.cell_acc, m, w.cell_box, w.cell_min, w.parent, w.comp_min);
-    PCH_LAUNCH("db_union0", db_union_k<0>, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
+    PCH_LAUNCH("db_union0", db_union_face_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
                (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, (const uint8_t*)w.core_s,
                (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, w.parent);
     PCH_LAUNCH("db_flatten", db_flatten_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
                w.parent, m);
-    PCH_LAUNCH("db_union1", db_union_k<1>, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
+    PCH_LAUNCH("db_union1", db_union_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
                (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, (const uint8_t*)w.core_s,
                (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, w.parent);
     PCH_LAUNCH("db_flatten", db_flatten_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
