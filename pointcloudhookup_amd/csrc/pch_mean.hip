@@ -266,7 +266,19 @@ __device__ __forceinline__ uint32_t ms_block_exact(const float* __restrict__ xyz
     const int l = lane_id();
     const int64_t p0 = blk * MSB;
     const int cnt = (int)((n - p0) < MSB ? (n - p0) : MSB);
-    for (int i = l; i < cnt; i += 64) stage[ms_pad(i)] = xyz[3 * (p0 + i) + c];
+    {
+        float v[MSB / 64];                               // all 16 loads in flight before the first LDS write
+#pragma unroll
+        for (int k = 0; k < MSB / 64; ++k) {
+            const int i = l + 64 * k;
+            v[k] = i < cnt ? xyz[3 * (p0 + i) + c] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < MSB / 64; ++k) {
+            const int i = l + 64 * k;
+            if (i < cnt) stage[ms_pad(i)] = v[k];
+        }
+    }
     __syncthreads();
     int pos = 0;                        // serial_len (kept across calls) grows while the parallel
                                         // passes make little progress and falls back when they do
