@@ -60,6 +60,26 @@ struct Arena {
     void   reset(size_t m) { off = m; }
 };
 
+// ---------------------------------------------------------------- small device -> host reads
+// A few words the host needs to size the next launch, without draining the stream: the copy lands
+// in a pinned per-thread buffer and the host waits for an event recorded right behind it, so
+// kernels enqueued after the copy keep the GPU busy meanwhile.  (pch_core.hip)
+struct HostPeek {
+    void*      pinned;          // 256 bytes of pinned host memory
+    hipEvent_t ev;
+    bool       ok;
+};
+HostPeek& host_peek();
+// enqueue: copy `bytes` (<= 256) from dev to the pinned buffer and record the event
+int peek_enqueue(const void* dev, size_t bytes, hipStream_t s);
+// wait for the copy, then memcpy to dst
+int peek_wait(void* dst, size_t bytes);
+
+// stage C with an early host copy of the cluster count (pch_dbscan.hip); k_host may be null
+int dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples, int64_t chunk_size,
+               const float* aabb_host, int32_t* labels, uint8_t* core, int32_t* out_nclusters,
+               void* ws, size_t ws_bytes, hipStream_t s, int32_t* k_host);
+
 // ---------------------------------------------------------------- profiling
 // When enabled every PCH_LAUNCH is bracketed by hipEvents recorded on the launch stream.
 void prof_begin_call();                       // (records accumulate until collected)

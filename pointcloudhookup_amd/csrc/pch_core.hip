@@ -72,6 +72,29 @@ void prof_pre(const char* name, hipStream_t s) {
 
 void prof_post(hipStream_t s) { (void)hipEventRecord(g_recs.back().e1, s); }
 
+HostPeek& host_peek() {
+    static thread_local HostPeek hp = {nullptr, nullptr, false};
+    if (!hp.ok) {
+        if (hipHostMalloc(&hp.pinned, 256, hipHostMallocDefault) == hipSuccess &&
+            hipEventCreateWithFlags(&hp.ev, hipEventDisableTiming) == hipSuccess)
+            hp.ok = true;
+    }
+    return hp;
+}
+int peek_enqueue(const void* dev, size_t bytes, hipStream_t s) {
+    HostPeek& hp = host_peek();
+    if (!hp.ok || bytes > 256) { set_error("pinned host buffer unavailable"); return PCH_ERR_HIP; }
+    PCH_HIP_TRY(hipMemcpyAsync(hp.pinned, dev, bytes, hipMemcpyDeviceToHost, s));
+    PCH_HIP_TRY(hipEventRecord(hp.ev, s));
+    return PCH_OK;
+}
+int peek_wait(void* dst, size_t bytes) {
+    HostPeek& hp = host_peek();
+    PCH_HIP_TRY(hipEventSynchronize(hp.ev));
+    memcpy(dst, hp.pinned, bytes);
+    return PCH_OK;
+}
+
 }  // namespace pch
 
 extern "C" {

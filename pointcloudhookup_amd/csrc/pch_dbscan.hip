@@ -1149,12 +1149,11 @@ extern "C" size_t pch_dbscan_ws_bytes(int64_t n) {
     return a.off;
 }
 
-extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t min_samples,
-                              int64_t chunk_size, const float* aabb_host, int32_t* labels,
-                              uint8_t* core, int32_t* out_nclusters, void* ws, size_t ws_bytes,
-                              void* stream) {
+int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples, int64_t chunk_size,
+                    const float* aabb_host, int32_t* labels, uint8_t* core, int32_t* out_nclusters, void* ws,
+                    size_t ws_bytes, hipStream_t s, int32_t* k_host) {
     prof_begin_call();
-    hipStream_t s = (hipStream_t)stream;
+    if (k_host) *k_host = 0;
     PCH_REQUIRE(n >= 0 && n < (int64_t(1) << 31), "n out of range [0, 2^31)");
     PCH_REQUIRE(eps > 0.0, "eps must be > 0 (sklearn: InvalidParameterError)");
     PCH_REQUIRE(min_samples >= 1, "min_samples must be >= 1 (sklearn: InvalidParameterError)");
@@ -1258,16 +1257,17 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
         PCH_LAUNCH("db_gather", db_gather_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, ks, vs, n, w.pts, w.head);
     }
     PCH_TRY(scan_exclusive_u32(w.head, w.head, n, w.scan_ws, w.meta + 7, s));
+    // the cell count sizes the next grids: fetch it while db_cells_k (sized by n) runs
     uint32_t st_m[2];
-    PCH_HIP_TRY(hipMemcpyAsync(st_m, w.meta + 6, sizeof(st_m), hipMemcpyDeviceToHost, s));
-    PCH_HIP_TRY(hipStreamSynchronize(s));
+    PCH_TRY(peek_enqueue(w.meta + 6, sizeof(st_m), s));
+    PCH_LAUNCH("db_cells", db_cells_k, dim3(gn), dim3(DB_THREADS), 0, s, ks, (const uint32_t*)w.head, n,
+               w.cid, w.cell_start, w.cell_key);
+    PCH_TRY(peek_wait(st_m, sizeof(st_m)));
     if (st_m[0] != 0) {
         set_error("finite coordinates outside the supplied bounding box");
         return PCH_ERR_ARG;
     }
     const int m = (int)st_m[1];
-    PCH_LAUNCH("db_cells", db_cells_k, dim3(gn), dim3(DB_THREADS), 0, s, ks, (const uint32_t*)w.head, n,
-               w.cid, w.cell_start, w.cell_key);
     const unsigned gc = (unsigned)ceil_div(m, DB_WAVES);
     const int2* rowtab = nullptr;
     if (m <= w.rowtab_cells) {
@@ -1299,6 +1299,8 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
     PCH_LAUNCH("db_mark", db_mark_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
                (const int*)w.root, (const int*)w.comp_min, m, w.flag);
     PCH_TRY(scan_exclusive_u32(w.flag, w.flag, n, w.scan_ws, w.meta + 8, s));
+    PCH_LAUNCH("db_finish", db_finish_k, dim3(1), dim3(64), 0, s, (const uint32_t*)(w.meta + 8), out_nclusters);
+    if (k_host) PCH_TRY(peek_enqueue(out_nclusters, sizeof(int32_t), s));    // read while the labels are written
     PCH_LAUNCH("db_label", db_label_k, dim3(gn), dim3(DB_THREADS), 0, s, (const float4*)w.pts,
                (const uint32_t*)w.cid, (const uint8_t*)w.core_s, (const int*)w.root,
                (const int*)w.comp_min, (const uint32_t*)w.flag, n, (const uint32_t*)w.cell_start,
@@ -1306,6 +1308,14 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
     PCH_LAUNCH("db_border", db_border_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
                (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, (const uint8_t*)w.core_s,
                (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, (const int*)w.cell_label, labels);
-    PCH_LAUNCH("db_finish", db_finish_k, dim3(1), dim3(64), 0, s, (const uint32_t*)(w.meta + 8), out_nclusters);
+    if (k_host) PCH_TRY(peek_wait(k_host, sizeof(int32_t)));
     return PCH_OK;
+}
+
+extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t min_samples,
+                              int64_t chunk_size, const float* aabb_host, int32_t* labels,
+                              uint8_t* core, int32_t* out_nclusters, void* ws, size_t ws_bytes,
+                              void* stream) {
+    return dbscan_run(xyz, n, eps, min_samples, chunk_size, aabb_host, labels, core, out_nclusters, ws, ws_bytes,
+                      (hipStream_t)stream, nullptr);
 }

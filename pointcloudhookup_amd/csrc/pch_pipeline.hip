@@ -58,8 +58,9 @@ extern "C" int pch_tower_clusters_f32(const float* raw, int64_t n, double pct, f
     PCH_TRY(pch_ground_filter_f32(raw, n, pct, offset, fallback_offset, min_keep, out_points, out_index,
                                   dev->scalars, &dev->count, dev->aabb, sub, sub_bytes, stream));
     DevInfo h;
-    PCH_HIP_TRY(hipMemcpyAsync(&h, dev, sizeof(DevInfo), hipMemcpyDeviceToHost, s));
-    PCH_HIP_TRY(hipStreamSynchronize(s));
+    static_assert(sizeof(DevInfo) <= 256, "fits the pinned peek buffer");
+    PCH_TRY(peek_enqueue(dev, sizeof(DevInfo), s));
+    PCH_TRY(peek_wait(&h, sizeof(DevInfo)));
     memcpy(info_host->centroid, h.scalars, 3 * sizeof(float));
     info_host->base = h.scalars[3];
     info_host->threshold = h.scalars[4];
@@ -78,11 +79,9 @@ extern "C" int pch_tower_clusters_f32(const float* raw, int64_t n, double pct, f
     }
     // ---- stage C (the filter's scratch is dead; its outputs are the caller's buffers)
     PCH_REQUIRE(out_labels != nullptr, "out_labels is null");
-    PCH_TRY(pch_dbscan_f32(out_points, nf, eps, min_samples, chunk_size, h.aabb, out_labels, nullptr,
-                           &dev->nclusters, sub, sub_bytes, stream));
-    int32_t k = 0;
-    PCH_HIP_TRY(hipMemcpyAsync(&k, &dev->nclusters, sizeof(k), hipMemcpyDeviceToHost, s));
-    PCH_HIP_TRY(hipStreamSynchronize(s));
+    int32_t k = 0;                                       // read back while the labels are still being written
+    PCH_TRY(dbscan_run(out_points, nf, eps, min_samples, chunk_size, h.aabb, out_labels, nullptr,
+                       &dev->nclusters, sub, sub_bytes, s, &k));
     info_host->nclusters = k;
     // ---- stage D0
     if (out_perm && out_offsets) {
