@@ -247,7 +247,10 @@ def tower_clusters(raw, eps=8.0, min_samples=80, chunk_size=50000, pct=25.0, off
     dev = raw.device
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     hint = _nf_hint.get(key)
-    caps = [n] if hint is None else [min(n, max(int(hint * 1.25) + 1024, 1 << 16)), n]
+    # output / workspace capacity for the kept points: the previous call's count with headroom, a
+    # quarter of the input on the first call; a call that keeps more is repeated once, sized for n
+    guess = n // 4 if hint is None else int(hint * 1.25) + 1024
+    caps = [min(n, max(guess, 1 << 16)), n]
     with torch.cuda.device(dev):
         out_points = torch.empty((n, 3), dtype=torch.float32, device=dev)
         out_index = torch.empty((n,), dtype=torch.int32, device=dev) if want_index else None
