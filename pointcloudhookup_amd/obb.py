@@ -123,3 +123,108 @@ def bounding_box_oriented(points, extent_order="unsorted"):
     (utils/tower_extraction.py:139,151,165)."""
     to_origin, extents = oriented_bounds(points, extent_order)
     return extents, np.linalg.inv(to_origin)
+
+
+# ---- many clusters at once -------------------------------------------------------------
+# The boxes of different clusters are independent, and qhull + the direction search hold the
+# GIL, so threads do not help.  PCH_OBB_WORKERS > 1 spreads the clusters over worker PROCESSES:
+# plain `python -m pointcloudhookup_amd.obb --worker` children that import only this module
+# (never the host application's main script, never a GPU context) and answer pickled requests
+# on their pipes.  Every cluster is still computed by bounding_box_oriented on the same points,
+# so the results are identical to the serial loop; results come back in input order.
+_WORKERS = []
+
+
+def _boxed(args):
+    points, extent_order = args
+    try:
+        return bounding_box_oriented(points, extent_order), None
+    except Exception as e:                    # reported per cluster, like the serial loop does
+        return None, e
+
+
+class _Worker:
+    def __init__(self):
+        import os
+        import subprocess
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ)
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        self.proc = subprocess.Popen([sys.executable, "-m", "pointcloudhookup_amd.obb", "--worker"],
+                                     stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+
+    def ask(self, args):
+        import pickle
+        pickle.dump(args, self.proc.stdin, protocol=pickle.HIGHEST_PROTOCOL)
+        self.proc.stdin.flush()
+        return pickle.load(self.proc.stdout)
+
+    def close(self):
+        try:
+            self.proc.stdin.close()
+            self.proc.wait(timeout=5)
+        except Exception:
+            self.proc.kill()
+
+
+def _workers(n):
+    import atexit
+    if not _WORKERS:
+        atexit.register(lambda: [w.close() for w in _WORKERS])
+    while len(_WORKERS) < n:
+        _WORKERS.append(_Worker())
+    return _WORKERS[:n]
+
+
+def boxes_of(clusters, extent_order="unsorted", workers=None):
+    """Yields ((extents, transform), None) or (None, exception) for every (n_k,3) array in
+    ``clusters``, in order.  workers: None -> PCH_OBB_WORKERS (default 1 = in this process)."""
+    import os
+    if workers is None:
+        workers = int(os.environ.get("PCH_OBB_WORKERS", "1") or "1")
+    clusters = list(clusters)
+    if workers <= 1 or len(clusters) < 2:
+        for c in clusters:
+            yield _boxed((c, extent_order))
+        return
+    import queue
+    import threading
+    tasks = queue.SimpleQueue()
+    for i, c in enumerate(clusters):
+        tasks.put((i, np.ascontiguousarray(c)))
+    results = [None] * len(clusters)
+
+    def serve(w):                              # one thread per worker process: request, answer, next
+        while True:
+            try:
+                i, c = tasks.get_nowait()
+            except queue.Empty:
+                return
+            try:
+                results[i] = w.ask((c, extent_order))
+            except Exception as e:            # a dead worker: compute here instead
+                results[i] = _boxed((c, extent_order)) if not isinstance(e, KeyboardInterrupt) else (None, e)
+
+    threads = [threading.Thread(target=serve, args=(w,), daemon=True)
+               for w in _workers(min(int(workers), len(clusters)))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    yield from results
+
+
+if __name__ == "__main__":
+    import pickle
+    import sys
+    if "--worker" in sys.argv:
+        inp, out = sys.stdin.buffer, sys.stdout.buffer
+        sys.stdout = sys.stderr                # stray prints must not corrupt the answer stream
+        while True:
+            try:
+                req = pickle.load(inp)
+            except EOFError:
+                break
+            pickle.dump(_boxed(req), out, protocol=pickle.HIGHEST_PROTOCOL)
+            out.flush()

@@ -65,10 +65,14 @@ def tower_table(clusters, aspect_ratio_threshold=0.8, min_height=15.0, max_width
     # one gather + one D2H copy for all clustered points (noise rows stay on the device)
     rows = perm[: int(offsets[k])].long()
     host_pts = pts.index_select(0, rows).cpu().numpy()
-    for label in range(k):
+    parts = [host_pts[offsets[label]:offsets[label + 1]] for label in range(k)]
+    # boxes of all clusters (PCH_OBB_WORKERS > 1: worker processes), consumed in label order
+    for label, (box, err) in enumerate(_obb.boxes_of(parts, extent_order)):
         try:
-            cluster_points = host_pts[offsets[label]:offsets[label + 1]]
-            extents, transform = _obb.bounding_box_oriented(cluster_points, extent_order)
+            cluster_points = parts[label]
+            if err is not None:
+                raise err
+            extents, transform = box
             height = extents[2]
             width = max(extents[0], extents[1])
             aspect_ratio = height / width

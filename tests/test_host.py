@@ -265,3 +265,22 @@ def test_dedup_centres_first_wins():
     assert tiles.dedup_centres(c, 30.0) == [0, 2, 4]          # 1 and 3 duplicate 0; 4 is 31 m from 2
     assert tiles.dedup_centres(np.zeros((0, 3))) == []
     assert tiles.reconcile(2, __import__("torch").zeros((2, 8)))[0:2] == (0, 2)   # single process
+
+
+def test_obb_worker_processes_return_the_serial_results():
+    """PCH_OBB_WORKERS > 1 (spawned worker processes) gives exactly the boxes of the serial loop,
+    in order, and reports a failing cluster the same way."""
+    from pointcloudhookup_amd import obb
+    rng = np.random.default_rng(5)
+    clusters = [(rng.normal(0, 1, (400 + 50 * i, 3)) * np.array([3.0, 2.0, 9.0 + i])).astype(np.float32)
+                for i in range(5)]
+    clusters.insert(2, np.zeros((3, 3), np.float32))            # degenerate: qhull raises
+    serial = list(obb.boxes_of(clusters, "unsorted", workers=1))
+    pooled = list(obb.boxes_of(clusters, "unsorted", workers=2))
+    assert len(serial) == len(pooled) == len(clusters)
+    for (b0, e0), (b1, e1) in zip(serial, pooled):
+        assert (e0 is None) == (e1 is None)
+        if e0 is None:
+            np.testing.assert_array_equal(b0[0], b1[0])
+            np.testing.assert_array_equal(b0[1], b1[1])
+    assert serial[2][1] is not None
