@@ -11,7 +11,7 @@
 //                  copied out for the percentile passes).  Per column and for the 24 useful
 //                  candidate binades E = emax+1 .. emax+24 (E <= emax: an element as large as
 //                  the sum; E > emax+24: every increment is 0) it stores the signed increment
-//                  sum S_E, one bound A0 = sum ceil|a/ulp(2^(emax+1))| (so that
+//                  sum S_E, one bound A0 >= sum |a/ulp(2^(emax+1))| (so that
 //                  sum|d_i| <= (A0 >> j) + 1024) and a tie bit per candidate (an element ties at
 //                  exactly one candidate: the one just above its lowest set bit).
 //   ms_level2_k  : rows for 64 blocks (65 536 points): child rows added at equal absolute binade.
@@ -40,7 +40,7 @@ struct MsHdr { int emax; uint32_t tie; uint32_t flags; uint32_t pad; };
 // block in ms_level2_k / ms_walk_k
 struct alignas(128) MsRec {
     MsHdr     h;
-    long long A0;                        // sum ceil|a / ulp(2^(emax+1))|
+    long long A0;                        // upper bound of sum |a / ulp(2^(emax+1))|
     long long S[MS_CAND];                // S[j] = sum_i rne(a_i / 2^j ulps)
     uint32_t  fix[MS_CAND];              // sparse-tie adjustments (adj0 & 0xFFFF) | adj1 << 16
     uint32_t  pad[18];
@@ -53,6 +53,37 @@ static_assert(sizeof(MsRec) == 384 && offsetof(MsRec, A0) == 16 && offsetof(MsRe
 // slots 0..23 = N0_j, 24..47 = N1_j, 48..71 = A_j (MS_ROW2 planes)
 __host__ __device__ __forceinline__ int64_t ms_at(int c, int slot, int64_t blk, int64_t nblk, int planes) {
     return ((int64_t)c * planes + slot) * nblk + blk;
+}
+
+// ---- wave-wide reductions without the LDS crossbar (all 64 lanes must be active) ------------
+// Inside a row of 16 lanes: DPP rotations folded into the ALU instruction; across rows and halves:
+// the gfx950 lane-swap instructions (v_permlane16_swap / v_permlane32_swap) exchange the odd rows
+// (upper half) of one register with the even rows (lower half) of another, which is exactly one
+// step of a transposed butterfly: two registers in, op(a', b') holds the pair results of the
+// first register in the even rows (lower half) and of the second one in the odd rows (upper half).
+template <int CTRL>
+__device__ __forceinline__ uint32_t ms_dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+constexpr int MS_ROR8 = 0x128, MS_ROR4 = 0x124, MS_ROR2 = 0x122, MS_ROR1 = 0x121;   // rotate inside a row of 16
+constexpr int MS_HALF_MIRROR = 0x141;                  // lane i <-> 7 - i inside every 8 lanes
+constexpr int MS_QUAD_X1 = 0xB1, MS_QUAD_X2 = 0x4E;    // quad_perm [1,0,3,2] / [2,3,0,1]: lane ^ 1, lane ^ 2
+
+template <typename Op>
+__device__ __forceinline__ uint32_t ms_wave_all(uint32_t v, Op op) {     // every lane gets op over the wave
+    v = op(v, ms_dpp<MS_ROR8>(v));
+    v = op(v, ms_dpp<MS_ROR4>(v));
+    v = op(v, ms_dpp<MS_ROR2>(v));
+    v = op(v, ms_dpp<MS_ROR1>(v));
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = op(r[0], r[1]);
+    const auto q = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return op(q[0], q[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ long long ms_add_ror64(long long v) {         // v + (v of the lane the DPP control names)
+    const uint32_t lo = ms_dpp<CTRL>((uint32_t)v), hi = ms_dpp<CTRL>((uint32_t)((unsigned long long)v >> 32));
+    return v + (long long)(((unsigned long long)hi << 32) | lo);
 }
 
 // x/2^j is a rounding tie iff the lowest set bit of x is 2^(j-1): returns 1 << j for that j
@@ -106,7 +137,8 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
             const uint32_t u = __float_as_uint(a[i]) & 0x7FFFFFFFu;
             mx = u > mx ? u : mx;
         }
-        mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_reduce_max(mx));
+        mx = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)ms_wave_all(mx, [](uint32_t a, uint32_t b) { return a > b ? a : b; }));
         const bool nonfinite = mx >= 0x7F800000u;             // |bits| order: inf / NaN are the largest
         const int ef = (int)(mx >> 23);
         const int emax = (ef > 0 ? ef : 1) - 127;
@@ -114,10 +146,7 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         // (nearest-even) and the integer difference of the two bit patterns is exactly that
         // multiple, so one float add + one integer add per (element, candidate); |x| < 2^23 keeps
         // the sum inside the constant's binade.  The 32-bit accumulators wrap; the true sums
-        // (|S| <= 2^27 per lane) are recovered after subtracting the constants.
-        uint32_t acc[MS_CAND];
-#pragma unroll
-        for (int j = 0; j < MS_CAND; ++j) acc[j] = 0;
+        // (|S| <= 2^27 per lane) are what is left once the 16 constants are taken off again.
         uint32_t tie = 0;
         int A0 = 0;
         const bool live = !nonfinite && mx != 0;               // wave-uniform
@@ -125,10 +154,16 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
 #pragma unroll
         for (int j = 0; j < MS_CAND; ++j) S[j] = 0;
         if (live) {
+            uint32_t acc[MS_CAND];                             // start at minus the 16 constants that get added
+            acc[0] = 0;
+#pragma unroll
+            for (int j = 1; j < MS_CAND; ++j)
+                acc[j] = 0u - (uint32_t)MS_PER * __float_as_uint((float)(3ull << (22 + j)));
+            float absum = 0.0f;
 #pragma unroll
             for (int i = 0; i < MS_PER; ++i) {
                 const float x = ldexpf(a[i], 22 - emax);       // a / ulp(2^(emax+1)), |x| < 2^23, exact
-                A0 += (int)ceilf(fabsf(x));
+                absum += fabsf(x);
                 tie |= ms_tie_bit(x);
                 acc[0] += (uint32_t)(int)rintf(x);
 #pragma unroll
@@ -137,16 +172,13 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
                     acc[j] += __float_as_uint(x + magic);
                 }
             }
-            S[0] = (int)acc[0];
 #pragma unroll
-            for (int j = 1; j < MS_CAND; ++j) {
-                const float magic = (float)(3ull << (22 + j));
-                S[j] = (int)(acc[j] - (uint32_t)MS_PER * __float_as_uint(magic));
-            }
+            for (int j = 0; j < MS_CAND; ++j) S[j] = (int)acc[j];
+            // A0 only has to be an upper bound of sum |x|: the float32 sum of 16 terms is low by at most
+            // 16 roundings (relative 2^-20), which the factor and the + 1 cover (|absum| < 2^27)
+            A0 = (int)ceilf(absum * 1.00001f) + 1;
         }
-        tie &= (1u << MS_CAND) - 1u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) tie |= __shfl_xor(tie, o, 64);
+        tie = ms_wave_all(tie & ((1u << MS_CAND) - 1u), [](uint32_t a, uint32_t b) { return a | b; });
         // ---- sparse ties (candidates >= MS_FIX_FROM with at most MS_FIX_MAX tie elements): every tie
         // leaves the running mantissa EVEN, and before it the parity is (incoming parity) ^ (parity of
         // the increments in front of it), which a few ballots give.  So the block's net increment is
@@ -187,26 +219,41 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
                 if (l == j) myfix = ((uint32_t)adj0 & 0xFFFFu) | ((uint32_t)adj1 << 16);
             }
         }
-        const long long A0w = wave_reduce_add((long long)A0);
+        long long A0w;
+        {
+            uint32_t r = (uint32_t)A0;                         // per lane <= 2^27: a row of 16 fits 32 bits
+            r += ms_dpp<MS_ROR8>(r); r += ms_dpp<MS_ROR4>(r); r += ms_dpp<MS_ROR2>(r); r += ms_dpp<MS_ROR1>(r);
+            const auto p = __builtin_amdgcn_permlane16_swap(r, r, false, false);
+            const unsigned long long two = (unsigned long long)p[0] + p[1];
+            const uint32_t lo = (uint32_t)two, hi = (uint32_t)(two >> 32);
+            const auto ql = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+            const auto qh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+            A0w = (long long)((((unsigned long long)qh[0] << 32) | ql[0]) + (((unsigned long long)qh[1] << 32) | ql[1]));
+        }
         // transposed reduction: 24 -> 12 -> 6 -> 3 values per lane while summing over the lane
-        // bits 5,4,3 (|partial| <= 2^30 stays in 32 bit), then three 64-bit butterfly steps
+        // bits 5,4,3 (|partial| <= 2^30 stays in 32 bit), then three 64-bit steps inside the 8-lane
+        // groups.  Bits 5 and 4 are lane-swap steps (see ms_wave_all), bit 3 a select + DPP rotation.
         int v12[12], v6[6], v3[3];
 #pragma unroll
-        for (int i = 0; i < 12; ++i)
-            v12[i] = (b5 ? S[12 + i] : S[i]) + __shfl_xor(b5 ? S[i] : S[12 + i], 32, 64);
+        for (int i = 0; i < 12; ++i) {
+            const auto r = __builtin_amdgcn_permlane32_swap((uint32_t)S[i], (uint32_t)S[12 + i], false, false);
+            v12[i] = (int)(r[0] + r[1]);                       // lower half: candidate i, upper half: 12 + i
+        }
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-            v6[i] = (b4 ? v12[6 + i] : v12[i]) + __shfl_xor(b4 ? v12[i] : v12[6 + i], 16, 64);
+        for (int i = 0; i < 6; ++i) {
+            const auto r = __builtin_amdgcn_permlane16_swap((uint32_t)v12[i], (uint32_t)v12[6 + i], false, false);
+            v6[i] = (int)(r[0] + r[1]);                        // even rows: candidate i, odd rows: 6 + i
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            v3[i] = (b3 ? v6[3 + i] : v6[i]) + __shfl_xor(b3 ? v6[i] : v6[3 + i], 8, 64);
+            v3[i] = (b3 ? v6[3 + i] : v6[i]) + (int)ms_dpp<MS_ROR8>((uint32_t)(b3 ? v6[i] : v6[3 + i]));
         long long t[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             t[i] = v3[i];
-            t[i] += __shfl_xor(t[i], 4, 64);
-            t[i] += __shfl_xor(t[i], 2, 64);
-            t[i] += __shfl_xor(t[i], 1, 64);
+            t[i] = ms_add_ror64<MS_HALF_MIRROR>(t[i]);         // lanes (i, 7-i), then (l, l^1), (l, l^2): every lane
+            t[i] = ms_add_ror64<MS_QUAD_X1>(t[i]);             // of an 8-lane group ends with the group's total
+            t[i] = ms_add_ror64<MS_QUAD_X2>(t[i]);
         }
         MsRec* rec = &stage[wave_id()];
         if ((l & 7) == 0) {
