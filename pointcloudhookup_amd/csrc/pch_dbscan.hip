@@ -202,6 +202,7 @@ constexpr int CS_WAVES   = CS_THREADS / 64;
 constexpr int CS_ROUNDS  = 4;
 constexpr int CS_TILE    = CS_THREADS * CS_ROUNDS;
 constexpr int CS_PASSES  = 4;
+constexpr int CS_HREP    = 8;         // copies of every digit histogram (power of two)
 constexpr int64_t CS_MAX_CHUNK = 1 << 17;     // larger chunks use the global sort
 
 // cell key of a row inside its chunk (0 when the row is outside the grid); ok = inside
@@ -223,7 +224,8 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
 #define CS_STAMP()
 #endif
     CS_STAMP();
-    __shared__ uint32_t hist[CS_PASSES][256];
+    __shared__ uint32_t hist[CS_PASSES][CS_HREP][256];   // replicated: lanes of a wave that share a bin (most do: a
+                                                         // chunk covers few cells) spread over CS_HREP addresses
     __shared__ uint32_t cnt[CS_WAVES][256];
     __shared__ uint32_t off[CS_WAVES][256];
     __shared__ uint32_t base[256];
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
     const int cn = (int)((n - lo) < g.chunk_size ? (n - lo) : g.chunk_size);
     const uint32_t mask = (1u << dbits) - 1u;
     const Row3* __restrict__ rows = reinterpret_cast<const Row3*>(xyz) + lo;
-    for (int j = tid; j < CS_PASSES * 256; j += CS_THREADS) (&hist[0][0])[j] = 0;
+    for (int j = tid; j < CS_PASSES * CS_HREP * 256; j += CS_THREADS) (&hist[0][0][0])[j] = 0;
     for (int j = tid; j < CS_WAVES * 256; j += CS_THREADS) (&cnt[0][0])[j] = 0;
     if (tid < 2) flags[tid] = 0;
     __syncthreads();
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
             if (in && !fin) flags[0] = 1u;
             else if (in && !ok) flags[1] = 1u;
             if (in)
-                for (int p = 0; p < passes; ++p) atomicAdd(&hist[p][(k >> (p * dbits)) & mask], 1u);
+                for (int p = 0; p < passes; ++p) atomicAdd(&hist[p][l & (CS_HREP - 1)][(k >> (p * dbits)) & mask], 1u);
         }
     }
     __syncthreads();
@@ -290,7 +292,9 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
         // exclusive scan of this pass' histogram
         uint32_t hv = 0, incl = 0;
         if (tid < 256) {
-            hv = hist[p][tid];
+            hv = 0;
+#pragma unroll
+            for (int r = 0; r < CS_HREP; ++r) hv += hist[p][r][tid];
             incl = wave_scan_incl(hv);
             if (l == 63) wsum[w] = incl;
         }

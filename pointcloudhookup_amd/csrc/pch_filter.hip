@@ -14,6 +14,7 @@ namespace pch {
 // selected order statistics only.
 // =====================================================================================
 constexpr int SEL_BINS = 4096;
+constexpr int SEL_REP0 = 4;             // histogram copies in the first pass
 constexpr int SEL_TILE = 4096;          // values per workgroup trip in the histogram passes
 
 struct SelState {
@@ -55,15 +56,19 @@ template <int PASS>
 __global__ __launch_bounds__(256) void sel_hist_k(const float* __restrict__ base, int64_t n,
                                                   int64_t stride, SelState* __restrict__ st,
                                                   uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[SEL_BINS];
-    for (int j = threadIdx.x; j < SEL_BINS; j += 256) h[j] = 0;
+    // pass 0 sees a handful of hot bins (z of a flat corridor): SEL_REP0 copies of the histogram, picked
+    // by lane, divide the same-address serialisation of the LDS atomics
+    constexpr int REP = PASS == 0 ? SEL_REP0 : 1;
+    __shared__ uint32_t hh[REP][SEL_BINS];
+    for (int j = threadIdx.x; j < REP * SEL_BINS; j += 256) (&hh[0][0])[j] = 0;
     __syncthreads();
+    uint32_t* h = hh[lane_id() & (REP - 1)];
     const uint32_t prefix = st->prefix;
     unsigned long long nans = 0;
     auto take = [&](bool in, float v) {
         const uint32_t k = sel_key(v);
         if (PASS == 0) {
-            sel_hist_add<3>(h, in, k >> 20);                  // z of a flat corridor: a handful of bins
+            if (in) atomicAdd(&h[k >> 20], 1u);
             nans += (in && v != v);
         } else if (PASS == 1) {
             sel_hist_add<1>(h, in && (k >> 20) == prefix, (k >> 8) & 0xFFFu);
@@ -94,8 +99,12 @@ __global__ __launch_bounds__(256) void sel_hist_k(const float* __restrict__ base
     }
     __syncthreads();
     const int nb = (PASS == 2) ? 256 : SEL_BINS;
-    for (int j = threadIdx.x; j < nb; j += 256)
-        if (h[j]) atomicAdd(&hist[j], h[j]);
+    for (int j = threadIdx.x; j < nb; j += 256) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int r = 0; r < REP; ++r) t += hh[r][j];
+        if (t) atomicAdd(&hist[j], t);
+    }
     if (PASS == 0) {
         nans = wave_reduce_add(nans);
         if (lane_id() == 0 && nans) atomicAdd(&st->nan_count, nans);
