@@ -1007,7 +1007,17 @@ __global__ __launch_bounds__(DB_THREADS) void db_mark_k(const int* __restrict__ 
                                                         uint32_t* __restrict__ flag) {
     const int c = blockIdx.x * DB_THREADS + threadIdx.x;
     if (c >= m) return;
-    if (root[c] == c) flag[comp_min[c]] = 1u;
+    if (root[c] == c) {                                    // one bit per original row: the smallest core row of a cluster
+        const uint32_t r = (uint32_t)comp_min[c];
+        atomicOr(&flag[r >> 5], 1u << (r & 31u));
+    }
+}
+
+// words of the row bitmap -> their population counts (the scan input)
+__global__ __launch_bounds__(DB_THREADS) void db_popc_k(const uint32_t* __restrict__ bits, int64_t nw,
+                                                        uint32_t* __restrict__ cnt) {
+    const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i < nw) cnt[i] = (uint32_t)__popc(bits[i]);
 }
 
 // labels of core points (original order), label of every cell, optional core mask
@@ -1016,6 +1026,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_label_k(const float4* __restric
                                                          const uint8_t* __restrict__ core_s,
                                                          const int* __restrict__ root,
                                                          const int* __restrict__ comp_min,
+                                                         const uint32_t* __restrict__ bits,
                                                          const uint32_t* __restrict__ rank, int64_t n,
                                                          const uint32_t* __restrict__ cell_start,
                                                          int* __restrict__ cell_label,
@@ -1025,7 +1036,11 @@ __global__ __launch_bounds__(DB_THREADS) void db_label_k(const float4* __restric
     if (i >= n) return;
     const uint32_t c = cid[i];
     const int r = root[c];
-    const int lab = r >= 0 ? (int)rank[comp_min[r]] : INT_BIG;
+    int lab = INT_BIG;
+    if (r >= 0) {                                          // clusters are numbered by their smallest core row
+        const uint32_t row = (uint32_t)comp_min[r];
+        lab = (int)(rank[row >> 5] + (uint32_t)__popc(bits[row >> 5] & ((1u << (row & 31u)) - 1u)));
+    }
     const uint32_t o = __float_as_uint(pts[i].w);
     const bool is_core = core_s[i] != 0;
     labels[o] = is_core ? lab : -1;
@@ -1124,7 +1139,7 @@ static void db_plan(Arena& a, int64_t n, DbWs& w) {
     w.root = a.take<int>(nn);
     w.comp_min = a.take<int>(nn);
     w.cell_label = a.take<int>(nn);
-    w.flag = a.take<uint32_t>(nn + 8);
+    w.flag = a.take<uint32_t>(nn / 16 + 256);             // row bitmap (n/32 words) + its scanned word counts
     w.radix_ws = a.take<uint32_t>(radix_ws_u32(nn));
     w.scan_ws = a.take<uint32_t>(scan_ws_u32(nn));
     // neighbour-row table (200 B per cell) for up to max(n/4, 64Ki) cells; beyond that the rows are
@@ -1295,19 +1310,24 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
     PCH_LAUNCH("db_union1", db_union_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
                (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, (const uint8_t*)w.core_s,
                (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, w.parent);
-    PCH_LAUNCH("db_flatten", db_flatten_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
-               w.parent, m);
     PCH_LAUNCH("db_compmin", db_compmin_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
                (const int*)w.cell_min, (const uint32_t*)w.cell_ncore, m, w.parent, w.root, w.comp_min);
-    PCH_HIP_TRY(hipMemsetAsync(w.flag, 0, sizeof(uint32_t) * (size_t)n, s));
+    // cluster id = rank of the cluster's smallest core row: a bitmap over the rows + a scan of its
+    // word counts (n/32 elements instead of n)
+    const int64_t nw = ceil_div(n, 32);
+    uint32_t* bits = w.flag;
+    uint32_t* wrank = w.flag + ((nw + 63) & ~int64_t(63));
+    PCH_HIP_TRY(hipMemsetAsync(bits, 0, sizeof(uint32_t) * (size_t)nw, s));
     PCH_LAUNCH("db_mark", db_mark_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
-               (const int*)w.root, (const int*)w.comp_min, m, w.flag);
-    PCH_TRY(scan_exclusive_u32(w.flag, w.flag, n, w.scan_ws, w.meta + 8, s));
+               (const int*)w.root, (const int*)w.comp_min, m, bits);
+    PCH_LAUNCH("db_popc", db_popc_k, dim3((unsigned)ceil_div(nw, DB_THREADS)), dim3(DB_THREADS), 0, s,
+               (const uint32_t*)bits, nw, wrank);
+    PCH_TRY(scan_exclusive_u32(wrank, wrank, nw, w.scan_ws, w.meta + 8, s));
     PCH_LAUNCH("db_finish", db_finish_k, dim3(1), dim3(64), 0, s, (const uint32_t*)(w.meta + 8), out_nclusters);
     if (k_host) PCH_TRY(peek_enqueue(out_nclusters, sizeof(int32_t), s));    // read while the labels are written
     PCH_LAUNCH("db_label", db_label_k, dim3(gn), dim3(DB_THREADS), 0, s, (const float4*)w.pts,
                (const uint32_t*)w.cid, (const uint8_t*)w.core_s, (const int*)w.root,
-               (const int*)w.comp_min, (const uint32_t*)w.flag, n, (const uint32_t*)w.cell_start,
+               (const int*)w.comp_min, (const uint32_t*)bits, (const uint32_t*)wrank, n, (const uint32_t*)w.cell_start,
                w.cell_label, labels, core);
     PCH_LAUNCH("db_border", db_border_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
                (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, (const uint8_t*)w.core_s,

@@ -300,7 +300,8 @@ static SideStream& side_stream() {
 // relaxed atomic), then writes the centred survivors and folds their bounding box into one of
 // 64 slot sets.  The sweep runs with the first threshold (offset); only if that keeps fewer than
 // min_keep points (utils/tower_extraction.py:87-89) a second sweep with the fallback threshold
-// overwrites the output - its workgroups return at once otherwise.
+// overwrites the output - its workgroups return at once otherwise (the last tile of the first sweep
+// sets the switch).
 // =====================================================================================
 constexpr int GF_THREADS = 256;
 constexpr int GF_ROUNDS  = 64;
@@ -364,7 +365,8 @@ template <int WHICH>
 __global__ __launch_bounds__(GF_THREADS) void gf_compact_k(
     const float* __restrict__ raw, const float* __restrict__ zcol, int64_t n,
     const float* __restrict__ centroid, const float* __restrict__ scal, GfState* __restrict__ st,
-    uint64_t* __restrict__ status, float* __restrict__ out_points, int32_t* __restrict__ out_index) {
+    uint64_t* __restrict__ status, long long min_keep, float* __restrict__ out_points,
+    int32_t* __restrict__ out_index) {
     __shared__ uint32_t wtot[GF_THREADS / 64];
     __shared__ uint32_t excl_sh;
     __shared__ uint32_t box[GF_THREADS / 64][6];
@@ -392,7 +394,10 @@ __global__ __launch_bounds__(GF_THREADS) void gf_compact_k(
         const uint32_t e = gf_lookback(status, blockIdx.x, T);
         if (l == 0) {
             excl_sh = e;
-            if (blockIdx.x == gridDim.x - 1) st->total[WHICH] = e + T;
+            if (blockIdx.x == gridDim.x - 1) {                // the last tile knows the total: it also decides
+                st->total[WHICH] = e + T;                     // whether the fallback threshold applies
+                if (WHICH == 0) st->use_b = ((long long)(e + T) < min_keep) ? 1u : 0u;
+            }
         }
     }
     __syncthreads();
@@ -439,11 +444,6 @@ __global__ __launch_bounds__(GF_THREADS) void gf_compact_k(
         for (int w2 = 1; w2 < GF_THREADS / 64; ++w2) v = box[w2][a] > v ? box[w2][a] : v;
         if (v) atomicMax(&st->slots[WHICH][blockIdx.x % GF_SLOTS][a], v);
     }
-}
-
-// after the first sweep: does the fallback threshold apply (utils/tower_extraction.py:87-89)?
-__global__ void gf_decide_k(GfState* __restrict__ st, long long min_keep) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) st->use_b = ((long long)st->total[0] < min_keep) ? 1u : 0u;
 }
 
 // publishes the scalars, the count and the bounding box of the sweep that counts
@@ -585,10 +585,11 @@ extern "C" int pch_ground_filter_f32(const float* raw, int64_t n, double pct, fl
     PCH_HIP_TRY(hipMemsetAsync(w.st, 0, w.clear_bytes, s));
     const dim3 grid((unsigned)nb), blk(GF_THREADS);
     PCH_LAUNCH("gf_compact", gf_compact_k<0>, grid, blk, 0, s, raw, (const float*)w.zcol, n,
-               (const float*)w.centroid, (const float*)w.sel.scal, w.st, w.status, out_points, out_index);
-    PCH_LAUNCH("gf_decide", gf_decide_k, dim3(1), dim3(64), 0, s, w.st, (long long)min_keep);
+               (const float*)w.centroid, (const float*)w.sel.scal, w.st, w.status, (long long)min_keep, out_points,
+               out_index);
     PCH_LAUNCH("gf_compact_fb", gf_compact_k<1>, grid, blk, 0, s, raw, (const float*)w.zcol, n,
-               (const float*)w.centroid, (const float*)w.sel.scal, w.st, w.status + nb, out_points, out_index);
+               (const float*)w.centroid, (const float*)w.sel.scal, w.st, w.status + nb, (long long)min_keep, out_points,
+               out_index);
     PCH_LAUNCH("gf_finalize", gf_finalize_k, dim3(1), dim3(64), 0, s, (const GfState*)w.st,
                (const float*)w.centroid, (const float*)w.sel.scal, out_scalars, out_count, out_aabb);
     return PCH_OK;
