@@ -62,11 +62,12 @@ def algorithmic_bytes(name, N, NF):
         "db_chunksort": 124 * NF,
         "db_keys": 24 * NF, "db_gather": 44 * NF, "db_cells": 24 * NF, "db_label": 33 * NF,
         "radix_hist": 8 * NF, "radix_scatter": 24 * NF, "scan_reduce": 4 * NF, "scan_apply": 8 * NF,
-        "seg_keys": 16 * NF, "seg_perm": 8 * NF, "seg_stats": 16 * NF,
-        "db_cellbox": 17 * NF, "db_compmin": 17 * NF,
+        "seg_keys": 16 * NF, "seg_perm": 8 * NF, "seg_stats": 16 * NF, "seg_hist": 4 * NF, "seg_scatter": 8 * NF,
+        "db_cellstats": 21 * NF,                                       # rows (16) + cell id (4) + core flag (1)
         # serial certified walk over the level-2 summary rows (3 columns x 400 B per 65 536 points):
         # a dependency chain on 3 wavefronts, bounded by latency, not by HBM or MFMA
-        "mean_walk": 3 * 400 * (N // 65536 + 1), "mean_level2": 3 * 216 * (N // 1024 + 1),
+        "mean_walk": 3 * 400 * (N // 65536 + 1),
+        "mean_level2": 3 * 384 * (N // 1024 + 1),                      # one 384-byte record per column and block
     }
     return table.get(name)
 
