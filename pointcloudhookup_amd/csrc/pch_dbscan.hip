@@ -1247,7 +1247,10 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
     const unsigned gn = (unsigned)ceil_div(n, DB_THREADS);
     PCH_HIP_TRY(hipMemsetAsync(w.meta + 6, 0, 4 * sizeof(uint32_t), s));
     const uint64_t* ks;
-    if (cellbits <= 32 && chunk_size <= CS_MAX_CHUNK) {
+    // PCH_DBSCAN_SORT=global forces the general path (tests compare the two)
+    const char* sort_mode = getenv("PCH_DBSCAN_SORT");
+    const bool force_global = sort_mode && strcmp(sort_mode, "global") == 0;
+    if (cellbits <= 32 && chunk_size <= CS_MAX_CHUNK && !force_global) {
         // chunk-local path: one workgroup per chunk builds keys, sorts and gathers
         const int passes = cellbits <= 0 ? 0 : (cellbits + 7) / 8;
         const int dbits = passes ? (cellbits + passes - 1) / passes : 1;

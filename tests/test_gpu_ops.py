@@ -326,3 +326,40 @@ def test_segment_by_label(cuda, n, K):
             np.testing.assert_array_equal(stats[k, :3], xyz[rows].min(0))
             np.testing.assert_array_equal(stats[k, 3:6], xyz[rows].max(0))
     np.testing.assert_array_equal(perm[offs[K]:], np.flatnonzero(labels == -1))
+
+
+def test_dbscan_chunk_local_sort_equals_global_sort(cuda, monkeypatch):
+    """The chunk-local cell sort (one workgroup per chunk) and the general global radix sort feed
+    the same clustering: labels and core masks must agree, with ragged last chunk, a NaN chunk and
+    a chunk size that is not a multiple of anything."""
+    rng = np.random.default_rng(11)
+    n = 123457
+    X = np.vstack([rng.normal([c, 50, 22], [3, 3, 10], (20000, 3)) for c in (100, 400, 700, 1000)]
+                  + [np.column_stack([rng.uniform(0, 1200, n - 80000), rng.uniform(0, 100, n - 80000),
+                                      rng.uniform(0, 30, n - 80000)])]).astype(np.float32)
+    X = X[rng.permutation(n)]
+    X[60001, 2] = np.nan
+    dev = _dev(X, cuda)
+    for chunk in (50000, 7777, 0):
+        monkeypatch.delenv("PCH_DBSCAN_SORT", raising=False)
+        la, ca, ka = ops.dbscan(dev, 8.0, 80, chunk, want_core=True)
+        monkeypatch.setenv("PCH_DBSCAN_SORT", "global")
+        lb, cb, kb = ops.dbscan(dev, 8.0, 80, chunk, want_core=True)
+        assert ka == kb
+        assert torch.equal(la, lb) and torch.equal(ca, cb)
+    monkeypatch.delenv("PCH_DBSCAN_SORT", raising=False)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1023, 1024, 1025, 16383, 16384, 16385, 32769, 70001])
+def test_ground_filter_sizes_around_tile_edges(cuda, n):
+    """Block (1024), compaction tile (16384) and wave (64) boundaries, single rows included."""
+    rng = np.random.default_rng(n)
+    raw = np.column_stack([rng.uniform(437000, 437300, n), rng.uniform(3139000, 3139100, n),
+                           80 + np.abs(rng.normal(0, 4.0, n))]).astype(np.float32)
+    ref = ogf.ground_filter(raw)
+    got = ops.ground_filter(_dev(raw, cuda))
+    np.testing.assert_array_equal(got["centroid"].view(np.uint32), ref["centroid"].view(np.uint32))
+    assert np.float32(got["base"]).view(np.uint32) == ref["base"].view(np.uint32)
+    assert got["used_fallback"] == ref["used_fallback"] and got["count"] == len(ref["filtered"])
+    np.testing.assert_array_equal(got["points"].cpu().numpy().view(np.uint32), ref["filtered"].view(np.uint32))
+    np.testing.assert_array_equal(got["index"].cpu().numpy(), np.flatnonzero(ref["keep"]))
