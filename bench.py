@@ -238,6 +238,48 @@ def main():
         except Exception as e:
             out["voxel_stage"] = {"error": str(e)}
 
+    # ---- tile stream side measurement (not in `value`): two host threads, each with its own HIP
+    # stream and workspace, work through tiles at the same time - one tile's latency-bound
+    # clustering overlaps the other's issue/bandwidth-bound filter.  Same tile as above.
+    if world == 1:
+        try:
+            import threading
+            per_thread, nthreads = max(2, args.steps), 2
+            errs = []
+
+            def worker(delay_s):
+                try:
+                    t_go = time.perf_counter() + delay_s         # staggered start: identical tiles would
+                    while time.perf_counter() < t_go:            # otherwise run their phases in lockstep
+                        pass
+                    st = torch.cuda.Stream(device=dev)
+                    with torch.cuda.stream(st):
+                        for _ in range(per_thread):
+                            pipeline.cluster_points(raw, EPS, MIN_POINTS, CHUNK)
+                        st.synchronize()
+                    ops.release_workspace()
+                except Exception as e:                           # pragma: no cover
+                    errs.append(str(e))
+
+            for rounds in (1, 2):                                # first round: warm-up (workspaces)
+                ths = [threading.Thread(target=worker, args=(0.45e-3 * ms_per_step * i,)) for i in range(nthreads)]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+                torch.cuda.synchronize()
+                dts = time.perf_counter() - t0
+            if errs:
+                raise RuntimeError(errs[0])
+            out["tile_stream"] = {"threads": nthreads, "tiles": nthreads * per_thread, "points_per_tile": N,
+                                  "ms_per_tile": round(1e3 * dts / (nthreads * per_thread), 3),
+                                  "Mpts_per_s": round(N * nthreads * per_thread / dts / 1e6, 1),
+                                  "note": "two tiles in flight on one GPU; not the headline value"}
+        except Exception as e:
+            out["tile_stream"] = {"error": str(e)}
+
     # ---- CPU baseline: the reference's own library calls (numpy + sklearn) on host cores
     if world == 1 and not args.no_cpu_baseline:
         try:
