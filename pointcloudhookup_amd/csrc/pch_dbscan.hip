@@ -920,6 +920,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_face_k(DbGrid g, const fl
     }
     const uint32_t as = cell_start[A], ae = cell_start[A + 1];
     const bool a_dense = ncoreA == (ae - as);
+    const float4 pa0 = pts[as];                            // in flight with the neighbour look-ups below
     uint32_t bs = 0, be = 0;
     bool b_dense = false, pend = false;
     float boxB[6] = {0, 0, 0, 0, 0, 0};
@@ -935,7 +936,12 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_face_k(DbGrid g, const fl
         if (pend) pend = parent[A] != parent[B];
     }
     if (gl != 0) pend = false;                             // one lane per group looks the roots up
-    if (pend) pend = uf_find(parent, A) != uf_find(parent, B);
+    int rootA = A, rootB = B;
+    if (pend) {
+        rootA = uf_find(parent, A);
+        rootB = uf_find(parent, B);
+        pend = rootA != rootB;
+    }
     pend = __shfl((int)pend, grp < 3 ? 21 * grp : 0, 64) != 0 && grp < 3;
     bool connected = false;
     uint32_t ia = as;
@@ -943,7 +949,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_face_k(DbGrid g, const fl
         if (__ballot(pend) == 0) break;
         if (!a_dense && !core_s[ia]) continue;
         ++tries;
-        const float4 pa = pts[ia];
+        const float4 pa = ia == as ? pa0 : pts[ia];
         bool near = pend && !(db_box_d2(pa, boxB) > g.eps2);
         const uint32_t maxlen = wave_reduce_max(near ? be - bs : 0u);
         for (uint32_t j0 = 0; j0 < maxlen; j0 += 21) {
@@ -954,7 +960,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_face_k(DbGrid g, const fl
             if (__ballot(near) == 0) break;
         }
     }
-    if (connected && gl == 0) uf_union(parent, A, B);
+    if (connected && gl == 0) uf_union(parent, rootA, rootB);      // starts from the roots found above
     // undecided pairs (rare): the full-wave search, one pair after the other
     unsigned long long todo = __ballot(pend && gl == 0);
     while (todo) {
