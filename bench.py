@@ -48,7 +48,12 @@ def knn_tile_bytes(points, eps, chunk):
                 pos = torch.searchsorted(uniq, nk).clamp(max=uniq.numel() - 1)
                 hit = uniq[pos] == nk
                 total += (cnt[pos] * hit).sum()
-    occ = dict(cells=int(uniq.numel()), max=int(cnt.max()), mean=float(cnt.double().mean()))
+    # occupancy histogram in power-of-two bins [2^k, 2^(k+1)) and the neighbour sum itself, so that the
+    # tile-model byte count can be recomputed: bytes = 12 * neighbour_points + 4 * points
+    bins = torch.floor(torch.log2(cnt.double())).long()
+    hist = torch.bincount(bins).tolist()
+    occ = dict(cells=int(uniq.numel()), max=int(cnt.max()), mean=float(cnt.double().mean()),
+               cell_side=eps, hist_log2=hist, neighbour_points=int(total), points=int(n))
     return int(12 * int(total) + 4 * n), occ
 
 
