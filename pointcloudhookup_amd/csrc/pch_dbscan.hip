@@ -763,6 +763,92 @@ __global__ __launch_bounds__(DB_THREADS) void db_cellfin_k(const uint32_t* __res
     comp_min[c] = INT_BIG;
 }
 
+// ---- wave-wide test: do cells A and B hold a pair of core points within eps? -------------------
+// A plain double loop finds a hit at once when most pairs are hits, but between two large cells
+// that touch only at a corner it can scan all of B for thousands of A points before it reaches one
+// that has a partner.  So first a few steps of alternating nearest-point descent (the point of A
+// nearest to B's box, its nearest point in B, that one's nearest point in A, ...) - every
+// candidate pair is checked with the exact predicate, so a hit is a proof; only if the descent
+// stalls above eps does the exhaustive search run, the A side filtered 64 points at a time.
+__device__ __forceinline__ float db_d2f(const float4& a, const float4& b) {
+    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+__device__ __forceinline__ float db_box_d2f(const float4& q, const float* __restrict__ box) {
+    const float gx = fmaxf(fmaxf(box[0] - q.x, q.x - box[3]), 0.0f);
+    const float gy = fmaxf(fmaxf(box[1] - q.y, q.y - box[4]), 0.0f);
+    const float gz = fmaxf(fmaxf(box[2] - q.z, q.z - box[5]), 0.0f);
+    return __builtin_fmaf(gz, gz, __builtin_fmaf(gy, gy, gx * gx));
+}
+// index of the core point of [s, e) that minimises f (lane-parallel, four loads in flight); -1: none
+template <typename F>
+__device__ __forceinline__ int db_argmin(const float4* __restrict__ pts, const uint8_t* __restrict__ core_s,
+                                         uint32_t s, uint32_t e, bool dense, F f) {
+    const int l = lane_id();
+    unsigned long long best = ~0ull;
+    for (uint32_t i0 = s; i0 < e; i0 += 256) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + 64 * u + l;
+            if (i < e && (dense || core_s[i])) {
+                const float d = f(pts[i]);
+                const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | i;   // d >= 0: bits order
+                best = k < best ? k : best;
+            }
+        }
+    }
+    best = wave_reduce_min(best);
+    return best == ~0ull ? -1 : (int)(uint32_t)best;
+}
+
+__device__ __forceinline__ bool db_cells_connected(const DbGrid& g, const float4* __restrict__ pts,
+                                                   const uint8_t* __restrict__ core_s, uint32_t as, uint32_t ae,
+                                                   bool a_dense, uint32_t bs, uint32_t be, bool b_dense,
+                                                   const float* __restrict__ boxB, uint32_t a_from) {
+    const int l = lane_id();
+    if (ae - as > 64 || be - bs > 64) {                    // descent only pays between larger cells
+        int ia = db_argmin(pts, core_s, as, ae, a_dense, [&](const float4& p) { return db_box_d2f(p, boxB); });
+        if (ia < 0) return false;
+        float4 q = pts[ia];
+        for (int it = 0; it < 3; ++it) {
+            const int jb = db_argmin(pts, core_s, bs, be, b_dense, [&](const float4& p) { return db_d2f(q, p); });
+            if (jb < 0) return false;
+            const float4 pb = pts[jb];
+            if (db_within2(q, pb, g)) return true;
+            const int ia2 = db_argmin(pts, core_s, as, ae, a_dense, [&](const float4& p) { return db_d2f(p, pb); });
+            const float4 pa = pts[ia2];
+            if (db_within2(pa, pb, g)) return true;
+            if (ia2 == ia) break;                          // a local minimum above eps: decide exhaustively
+            ia = ia2;
+            q = pa;
+        }
+    }
+    for (uint32_t a0 = a_from; a0 < ae; a0 += 64) {
+        const uint32_t ia = a0 + l;
+        float4 pa;
+        pa.x = pa.y = pa.z = pa.w = 0.0f;
+        bool near = false;
+        if (ia < ae && (a_dense || core_s[ia])) {
+            pa = pts[ia];
+            near = !(db_box_d2(pa, boxB) > g.eps2);
+        }
+        unsigned long long todo = __ballot(near);
+        while (todo) {
+            const int src = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            float4 q;
+            q.x = __shfl(pa.x, src, 64); q.y = __shfl(pa.y, src, 64); q.z = __shfl(pa.z, src, 64); q.w = 0.0f;
+            for (uint32_t j0 = bs; j0 < be; j0 += 64) {
+                const uint32_t j = j0 + l;
+                bool hit = false;
+                if (j < be && (b_dense || core_s[j])) hit = db_within2(q, pts[j], g);
+                if (__ballot(hit)) return true;
+            }
+        }
+    }
+    return false;
+}
+
 // ---- union-find over cells (hook larger root under smaller; lock free) ------------------
 // Invariant: parent[x] <= x, only roots (parent[x] == x) are ever hooked, and only by a CAS, so
 // every value ever stored in parent[x] is an ancestor of x.  Loads bypass the (incoherent) L1;
@@ -857,18 +943,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4*
             const uint32_t bs = cell_start[Bs], be = cell_start[Bs + 1];
             const bool b_dense = cell_ncore[Bs] == (be - bs);
             const float* boxB = cell_box + 6 * (int64_t)Bs;
-            bool connected = false;
-            for (uint32_t ia = as; ia < ae && !connected; ++ia) {
-                if (!a_dense && !core_s[ia]) continue;
-                const float4 pa = pts[ia];
-                if (db_box_d2(pa, boxB) > g.eps2) continue;
-                for (uint32_t j0 = bs; j0 < be; j0 += 64) {
-                    const uint32_t j = j0 + l;
-                    bool hit = false;
-                    if (j < be && (b_dense || core_s[j])) hit = db_within2(pa, pts[j], g);
-                    if (__ballot(hit)) { connected = true; break; }
-                }
-            }
+            const bool connected = db_cells_connected(g, pts, core_s, as, ae, a_dense, bs, be, b_dense, boxB, as);
             if (connected && l == 0) uf_union(parent, A, Bs);
         }
     }
@@ -970,18 +1045,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_face_k(DbGrid g, const fl
         const uint32_t bs2 = cell_start[Bs], be2 = cell_start[Bs + 1];
         const bool b_dense2 = cell_ncore[Bs] == (be2 - bs2);
         const float* boxB2 = cell_box + 6 * (int64_t)Bs;
-        bool conn = false;
-        for (uint32_t i2 = ia; i2 < ae && !conn; ++i2) {
-            if (!a_dense && !core_s[i2]) continue;
-            const float4 pa = pts[i2];
-            if (db_box_d2(pa, boxB2) > g.eps2) continue;
-            for (uint32_t j0 = bs2; j0 < be2; j0 += 64) {
-                const uint32_t j = j0 + l;
-                bool hit = false;
-                if (j < be2 && (b_dense2 || core_s[j])) hit = db_within2(pa, pts[j], g);
-                if (__ballot(hit)) { conn = true; break; }
-            }
-        }
+        const bool conn = db_cells_connected(g, pts, core_s, as, ae, a_dense, bs2, be2, b_dense2, boxB2, ia);
         if (conn && l == 0) uf_union(parent, A, Bs);
     }
 }
