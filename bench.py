@@ -88,6 +88,8 @@ def main():
                     help="offset: EPSG:4547-scale coordinates like the reference's data (default); "
                          "local: corridor starts at the origin")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tile-stream", action="store_true",
+                    help="skip the two-tiles-in-flight side measurement (profiling runs)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -246,36 +248,41 @@ def main():
     # ---- tile stream side measurement (not in `value`): two host threads, each with its own HIP
     # stream and workspace, work through tiles at the same time - one tile's latency-bound
     # clustering overlaps the other's issue/bandwidth-bound filter.  Same tile as above.
-    if world == 1:
+    if world == 1 and not args.no_tile_stream:
         try:
             import threading
             per_thread, nthreads = max(2, args.steps), 2
-            errs = []
+            errs, marks = [], {}
+            gate = threading.Barrier(nthreads + 1)
 
-            def worker(delay_s):
+            def worker(i):
                 try:
-                    t_go = time.perf_counter() + delay_s         # staggered start: identical tiles would
-                    while time.perf_counter() < t_go:            # otherwise run their phases in lockstep
-                        pass
                     st = torch.cuda.Stream(device=dev)
                     with torch.cuda.stream(st):
+                        pipeline.cluster_points(raw, EPS, MIN_POINTS, CHUNK)     # warm-up: this thread's workspace
+                        st.synchronize()
+                        gate.wait()
+                        t_go = time.perf_counter() + 0.45e-3 * ms_per_step * i    # staggered start: identical tiles
+                        while time.perf_counter() < t_go:                        # would run their phases in lockstep
+                            pass
                         for _ in range(per_thread):
                             pipeline.cluster_points(raw, EPS, MIN_POINTS, CHUNK)
                         st.synchronize()
+                    gate.wait()
                     ops.release_workspace()
                 except Exception as e:                           # pragma: no cover
                     errs.append(str(e))
+                    gate.abort()
 
-            for rounds in (1, 2):                                # first round: warm-up (workspaces)
-                ths = [threading.Thread(target=worker, args=(0.45e-3 * ms_per_step * i,)) for i in range(nthreads)]
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for t in ths:
-                    t.start()
-                for t in ths:
-                    t.join()
-                torch.cuda.synchronize()
-                dts = time.perf_counter() - t0
+            ths = [threading.Thread(target=worker, args=(i,)) for i in range(nthreads)]
+            for t in ths:
+                t.start()
+            gate.wait()
+            t0 = time.perf_counter()
+            gate.wait()
+            dts = time.perf_counter() - t0
+            for t in ths:
+                t.join()
             if errs:
                 raise RuntimeError(errs[0])
             out["tile_stream"] = {"threads": nthreads, "tiles": nthreads * per_thread, "points_per_tile": N,
