@@ -204,6 +204,7 @@ constexpr int CS_TILE    = CS_THREADS * CS_ROUNDS;
 constexpr int CS_PASSES  = 4;
 constexpr int CS_HREP    = 8;         // copies of every digit histogram (power of two)
 constexpr int64_t CS_MAX_CHUNK = 1 << 17;     // larger chunks use the global sort
+constexpr int64_t CS_MIN_CHUNKS = 96;         // fewer chunks: the global sort keeps more of the GPU busy
 
 // cell key of a row inside its chunk (0 when the row is outside the grid); ok = inside
 __device__ __forceinline__ uint32_t cs_cell_key(const DbGrid& g, float x, float y, float z, bool& ok) {
@@ -1317,10 +1318,12 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
     const unsigned gn = (unsigned)ceil_div(n, DB_THREADS);
     PCH_HIP_TRY(hipMemsetAsync(w.meta + 6, 0, 4 * sizeof(uint32_t), s));
     const uint64_t* ks;
-    // PCH_DBSCAN_SORT=global forces the general path (tests compare the two)
+    // One workgroup per chunk only pays with enough chunks to fill the GPU (measured break-even near
+    // 100 chunks of 50 000 rows); PCH_DBSCAN_SORT=chunk / global forces a path (tests compare them)
     const char* sort_mode = getenv("PCH_DBSCAN_SORT");
     const bool force_global = sort_mode && strcmp(sort_mode, "global") == 0;
-    if (cellbits <= 32 && chunk_size <= CS_MAX_CHUNK && !force_global) {
+    const bool force_chunk = sort_mode && strcmp(sort_mode, "chunk") == 0;
+    if (cellbits <= 32 && chunk_size <= CS_MAX_CHUNK && !force_global && (force_chunk || nchunks >= CS_MIN_CHUNKS)) {
         // chunk-local path: one workgroup per chunk builds keys, sorts and gathers
         const int passes = cellbits <= 0 ? 0 : (cellbits + 7) / 8;
         const int dbits = passes ? (cellbits + passes - 1) / passes : 1;

@@ -340,14 +340,15 @@ def test_dbscan_chunk_local_sort_equals_global_sort(cuda, monkeypatch):
     X = X[rng.permutation(n)]
     X[60001, 2] = np.nan
     dev = _dev(X, cuda)
-    for chunk in (50000, 7777, 0):
-        monkeypatch.delenv("PCH_DBSCAN_SORT", raising=False)
+    for chunk in (50000, 7777, 1000, 0):
+        monkeypatch.setenv("PCH_DBSCAN_SORT", "chunk")
         la, ca, ka = ops.dbscan(dev, 8.0, 80, chunk, want_core=True)
         monkeypatch.setenv("PCH_DBSCAN_SORT", "global")
         lb, cb, kb = ops.dbscan(dev, 8.0, 80, chunk, want_core=True)
-        assert ka == kb
-        assert torch.equal(la, lb) and torch.equal(ca, cb)
-    monkeypatch.delenv("PCH_DBSCAN_SORT", raising=False)
+        monkeypatch.delenv("PCH_DBSCAN_SORT", raising=False)       # the library's own choice (by chunk count)
+        lc, cc, kc = ops.dbscan(dev, 8.0, 80, chunk, want_core=True)
+        assert ka == kb == kc
+        assert torch.equal(la, lb) and torch.equal(ca, cb) and torch.equal(la, lc) and torch.equal(ca, cc)
 
 
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1023, 1024, 1025, 16383, 16384, 16385, 32769, 70001])
