@@ -230,7 +230,7 @@ def dbscan(xyz, eps=8.0, min_samples=80, chunk_size=50000, aabb=None, want_core=
 
 
 # ---------------------------------------------------------------------- stages B + C + D0
-_nf_hint = {}          # device index -> points kept by the previous call (sizes the next workspace)
+_nf_hint = {}          # device index -> fraction of points the previous call kept (sizes the next workspace)
 
 
 def tower_clusters(raw, eps=8.0, min_samples=80, chunk_size=50000, pct=25.0, offset=3.0,
@@ -247,9 +247,9 @@ def tower_clusters(raw, eps=8.0, min_samples=80, chunk_size=50000, pct=25.0, off
     dev = raw.device
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     hint = _nf_hint.get(key)
-    # output / workspace capacity for the kept points: the previous call's count with headroom, a
+    # output / workspace capacity for the kept points: the previous call's kept fraction with headroom, a
     # quarter of the input on the first call; a call that keeps more is repeated once, sized for n
-    guess = n // 4 if hint is None else int(hint * 1.25) + 1024
+    guess = n // 4 if hint is None else int(hint * n * 1.25) + 1024     # hint: kept fraction of the last tile
     caps = [min(n, max(guess, 1 << 16)), n]
     with torch.cuda.device(dev):
         out_points = torch.empty((n, 3), dtype=torch.float32, device=dev)
@@ -274,7 +274,7 @@ def tower_clusters(raw, eps=8.0, min_samples=80, chunk_size=50000, pct=25.0, off
             perm, offsets, stats = segment_by_label(labels[:nf], out_points[:nf], k)
             rc = 0
         _lib.check(rc)
-    _nf_hint[key] = nf
+    _nf_hint[key] = nf / max(n, 1)
     ground = dict(points=out_points[:nf], index=None if out_index is None else out_index[:nf],
                   centroid=np.array(info.centroid, dtype=np.float32), base=np.float32(info.base),
                   threshold=np.float32(info.threshold), used_fallback=bool(info.used_fallback),

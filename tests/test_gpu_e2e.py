@@ -216,7 +216,7 @@ def test_tower_clusters_equals_the_three_stage_calls(cuda):
     ops._nf_hint.pop(key, None)
     check(ops.tower_clusters(raw, want_index=True))                 # first call: sized for n
     check(ops.tower_clusters(raw, want_index=True))                 # sized from the hint
-    ops._nf_hint[key] = 1000                                        # hint far too small: retried with n
+    ops._nf_hint[key] = 1e-4                                        # hint far too small: retried with n
     check(ops.tower_clusters(raw, want_index=True))
     check(ops.tower_clusters(raw, want_index=True, k_cap=1))        # more clusters than k_cap
     g, l, kk, p, o, s = ops.tower_clusters(raw, segment=False)
