@@ -45,8 +45,12 @@ def cloud(n):
 
 
 it = 0
+t_say = time.time() + 30
 while time.time() < t_end:
     it += 1
+    if time.time() > t_say:                        # a line every half minute: long runs must not look hung
+        print("fuzz", it, stats, flush=True)
+        t_say = time.time() + 30
     n = int(rng.choice([1, 2, 63, 65, 1000, 1024, 5000, 16385, 40000, 100003, 262145, 700001]))
     raw = cloud(n)
     d = torch.from_numpy(raw).to(dev)
