@@ -35,6 +35,7 @@ struct DbGrid {
     int     mx, my, mz;          // largest valid cell coordinate per axis
     int64_t chunk_size;
     const uint32_t* chunk_bad;   // != 0: the chunk holds NaN/inf and stays noise as a whole
+    const uint32_t* chunk_cells; // [chunks + 1] first cell of every chunk (cells are sorted by chunk first)
     int     min_samples;
 };
 
@@ -402,18 +403,25 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
 
 __global__ __launch_bounds__(DB_THREADS) void db_cells_k(const uint64_t* __restrict__ keys,
                                                          const uint32_t* __restrict__ excl, int64_t n,
+                                                         int sh, int64_t nchunks,
                                                          uint32_t* __restrict__ cid,
                                                          uint32_t* __restrict__ cell_start,
-                                                         uint64_t* __restrict__ cell_key) {
+                                                         uint64_t* __restrict__ cell_key,
+                                                         uint32_t* __restrict__ chunk_cells) {
     const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
     if (i >= n) return;
-    const bool head = (i == 0 || keys[i] != keys[i - 1]);
+    const uint64_t key = keys[i], prev = i ? keys[i - 1] : 0;
+    const bool head = (i == 0 || key != prev);
     const uint32_t c = excl[i] + (head ? 1u : 0u) - 1u;
     cid[i] = c;
-    if (head) { cell_start[c] = (uint32_t)i; cell_key[c] = keys[i]; }
-    if (i == n - 1) cell_start[c + 1] = (uint32_t)n;
+    if (head) {
+        cell_start[c] = (uint32_t)i;
+        cell_key[c] = key;
+        const uint64_t ch = sh < 64 ? key >> sh : 0, pch = sh < 64 ? prev >> sh : 0;
+        if (i == 0 || ch != pch) chunk_cells[ch] = c;      // every chunk holds rows, hence cells
+    }
+    if (i == n - 1) { cell_start[c + 1] = (uint32_t)n; chunk_cells[nchunks] = c + 1; }
 }
-
 // ---- neighbour rows of one cell: lanes 0..24 each binary-search one (dy,dz) row ---------
 struct RowSet {
     int ca[DB_ROWS], cb[DB_ROWS];      // cell index range of every row
@@ -454,8 +462,9 @@ __device__ __forceinline__ void db_rows(const DbGrid& g, const uint64_t* __restr
         if (ny >= 0 && ny <= g.my && nz >= 0 && nz <= g.mz) {
             const int xlo = (int)cx - 2 < 0 ? 0 : (int)cx - 2;
             const int xhi = (int)cx + 2 > g.mx ? g.mx : (int)cx + 2;
-            a = db_lower(cell_key, m, db_pack(g, chunk, (uint64_t)nz, (uint64_t)ny, (uint64_t)xlo));
-            b = db_upper(cell_key, m, db_pack(g, chunk, (uint64_t)nz, (uint64_t)ny, (uint64_t)xhi));
+            const int c0 = (int)g.chunk_cells[chunk], c1 = (int)g.chunk_cells[chunk + 1];   // neighbours share the chunk
+            a = c0 + db_lower(cell_key + c0, c1 - c0, db_pack(g, chunk, (uint64_t)nz, (uint64_t)ny, (uint64_t)xlo));
+            b = c0 + db_upper(cell_key + c0, c1 - c0, db_pack(g, chunk, (uint64_t)nz, (uint64_t)ny, (uint64_t)xhi));
         }
         rs->ca[l] = a;
         rs->cb[l] = b;
@@ -481,8 +490,9 @@ __global__ __launch_bounds__(DB_THREADS) void db_rowtab_k(DbGrid g, const uint64
     if (ny >= 0 && ny <= g.my && nz >= 0 && nz <= g.mz) {
         const int xlo = (int)cx - 2 < 0 ? 0 : (int)cx - 2;
         const int xhi = (int)cx + 2 > g.mx ? g.mx : (int)cx + 2;
-        v.x = db_lower(cell_key, m, db_pack(g, chunk, (uint64_t)nz, (uint64_t)ny, (uint64_t)xlo));
-        v.y = db_upper(cell_key, m, db_pack(g, chunk, (uint64_t)nz, (uint64_t)ny, (uint64_t)xhi));
+        const int c0 = (int)g.chunk_cells[chunk], c1 = (int)g.chunk_cells[chunk + 1];   // neighbours share the chunk
+        v.x = c0 + db_lower(cell_key + c0, c1 - c0, db_pack(g, chunk, (uint64_t)nz, (uint64_t)ny, (uint64_t)xlo));
+        v.y = c0 + db_upper(cell_key + c0, c1 - c0, db_pack(g, chunk, (uint64_t)nz, (uint64_t)ny, (uint64_t)xhi));
     }
     rowtab[(int64_t)c * DB_ROWS + l] = v;
 }
@@ -1185,12 +1195,14 @@ struct DbWs {
     int2*     rowtab;
     int64_t   rowtab_cells;
     uint32_t* chunk_bad;
+    uint32_t* chunk_cells;
 };
 
 static void db_plan(Arena& a, int64_t n, DbWs& w) {
     const int64_t nn = n > 0 ? n : 1;
     w.meta = a.take<uint32_t>(16);
     w.chunk_bad = a.take<uint32_t>(nn + 8);              // one word per chunk (chunk_size >= 1)
+    w.chunk_cells = a.take<uint32_t>(nn + 8);
     w.k0 = a.take<uint64_t>(nn);
     w.k1 = a.take<uint64_t>(nn);
     w.v0 = a.take<uint32_t>(nn);
@@ -1296,6 +1308,7 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
     if (!(g.eps2_hi < 3.0e38f)) { g.eps2_lo = -1.0f; g.eps2_hi = NAN; }    // absurd eps: exact path only
     g.chunk_size = chunk_size;
     g.chunk_bad = w.chunk_bad;
+    g.chunk_cells = w.chunk_cells;
     g.min_samples = min_samples;
     double ext[3];
     int mc[3];
@@ -1356,7 +1369,7 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
     uint32_t st_m[2];
     PCH_TRY(peek_enqueue(w.meta + 6, sizeof(st_m), s));
     PCH_LAUNCH("db_cells", db_cells_k, dim3(gn), dim3(DB_THREADS), 0, s, ks, (const uint32_t*)w.head, n,
-               w.cid, w.cell_start, w.cell_key);
+               cellbits, nchunks, w.cid, w.cell_start, w.cell_key, w.chunk_cells);
     PCH_TRY(peek_wait(st_m, sizeof(st_m)));
     if (st_m[0] != 0) {
         set_error("finite coordinates outside the supplied bounding box");
