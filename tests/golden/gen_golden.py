@@ -14,11 +14,23 @@ committed files.  Nothing from /root/reference is copied: fixtures hold numbers 
                     in SURVEY.md section 8c are written.
   e2e_config1.npz   self-golden (flagged as such): oracle end-to-end result for BASELINE
                     config 1 (1 M-pt corridor, 3 towers)
+  refrun_*.npz      what the REFERENCE'S OWN utils/tower_extraction.py::extract_towers produced
+                    when executed here on seeded inputs (see reference_runs() below): its log
+                    lines, progress values, every cluster_points array it handed to trimesh
+                    (as per-cluster SHA-256 + the label vector they imply), the tower dicts it
+                    returned and the coordinates it handed to laspy for the per-tower files.
+                    The modules the reference imports but this image lacks are replaced by
+                    recorders: laspy (array-backed reader, recording writer), trimesh
+                    (PointCloud records the points; its bounding_box_oriented is
+                    oracle/obb.py - stage D1 stays PARITY UNPINNED), pandas (records the
+                    DataFrame rows), open3d (empty).  numpy and scikit-learn are the real
+                    libraries, called by the reference's own statements.
 """
 import json
 import os
 import sys
 import types
+import warnings
 
 import numpy as np
 
@@ -150,8 +162,268 @@ def e2e_config1():
            for o in res for k in ("center", "extent", "north_angle", "label")})
 
 
+# ---------------------------------------------------------------------------------------------
+# Reference-run fixtures: the reference's own extract_towers executed under recording modules.
+REF = "/root/reference"
+REFRUN_SCALES = np.array([0.001, 0.001, 0.001])
+REFRUN_OFFSETS = np.array([437000.0, 3139000.0, 0.0])
+
+
+def refrun_inputs(name):
+    """Seeded inputs of the reference-run cases.  Returns (x, y, z float64 as laspy would hand
+    them over, XYZ int32 | None, extract_towers kwargs).  Shared with the tests, which rebuild
+    the same inputs and check the checksum stored in the fixture."""
+    from pointcloudhookup_amd import synth
+
+    def quantise(pts):
+        XYZ = np.round((pts - REFRUN_OFFSETS) / REFRUN_SCALES).astype(np.int32)
+        cols = [XYZ[:, a].astype(np.float64) * REFRUN_SCALES[a] + REFRUN_OFFSETS[a] for a in range(3)]
+        return cols[0], cols[1], cols[2], XYZ
+
+    if name == "config1_1m":                     # BASELINE config 1: 1 M pts, 3 towers
+        pts = synth.corridor_numpy(1_000_000, seed=synth.SEED0, kind="corridor", offset=True, towers=3)
+        return (*quantise(pts), {})
+    if name == "towers5x3":                     # 5 towers, several 50k chunks cut through towers
+        rng = np.random.default_rng(77)
+        g = np.column_stack([rng.uniform(0, 300, 300_000), rng.uniform(0, 100, 300_000), rng.normal(0, 0.05, 300_000)])
+        tw = [np.column_stack([rng.normal(30 + 60 * t, 2.5, 24_000), rng.normal(50, 2.5, 24_000),
+                               np.clip(rng.normal(22, 9, 24_000), 0.5, 45)]) for t in range(5)]
+        clutter = np.column_stack([rng.uniform(0, 300, 3000), rng.uniform(0, 100, 3000), rng.uniform(3, 40, 3000)])
+        pts = np.vstack([g] + tw + [clutter]) + synth.GLOBAL_OFFSET
+        pts = pts[rng.permutation(len(pts))]
+        return (*quantise(pts), {})
+    if name == "fallback":                       # < 1000 survivors at +3.0 -> threshold +1.0 (:87-89)
+        rng = np.random.default_rng(501)
+        g = np.column_stack([rng.uniform(0, 300, 20000), rng.uniform(0, 100, 20000), rng.normal(0, 0.05, 20000)])
+        mid = np.column_stack([rng.normal(150, 2.0, 2500), rng.normal(50, 2.0, 2500), rng.uniform(1.2, 2.9, 2500)])
+        top = np.column_stack([rng.normal(150, 2.0, 600), rng.normal(50, 2.0, 600), rng.uniform(3.5, 25, 600)])
+        far = np.column_stack([rng.uniform(0, 300, 400), rng.uniform(0, 100, 400), rng.uniform(1.5, 2.5, 400)])
+        pts = np.vstack([g, mid, top, far]) + synth.GLOBAL_OFFSET
+        pts = pts[rng.permutation(len(pts))]
+        return (*quantise(pts), dict(eps=3.0, min_points=20, min_height=5.0, min_width=2, aspect_ratio_threshold=0.3))
+    if name == "nonfinite":                      # one NaN x: the centroid's x is NaN, every chunk fails in sklearn
+        pts = synth.corridor_numpy(300_000, seed=synth.SEED0 + 3, kind="corridor", offset=True, towers=3)
+        x, y, z, _ = quantise(pts)
+        x = x.copy()
+        x[123456] = np.nan
+        return x, y, z, None, {}
+    if name == "empty":                          # zero points: np.percentile raises, the filter stage returns []
+        e = np.zeros(0)
+        return e, e, e, np.zeros((0, 3), np.int32), {}
+    raise KeyError(name)
+
+
+REFRUN_CASES = ["config1_1m", "towers5x3", "fallback", "nonfinite", "empty"]
+
+
+def input_checksum(x, y, z):
+    import hashlib
+    h = hashlib.sha256()
+    for a in (x, y, z):
+        h.update(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+    return h.hexdigest()
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _recording_modules(registry, rec):
+    """Stand-ins for the modules the reference imports that this image lacks.  They hold no
+    algorithm of the hot path except trimesh's box fit, which is oracle/obb.py (unpinned)."""
+    from oracle import obb as oobb
+
+    laspy = types.ModuleType("laspy")
+
+    class _Header:
+        def __init__(self, point_format=3, version=(1, 2)):
+            self.point_format, self.version = point_format, version
+            self.scales, self.offsets = REFRUN_SCALES.copy(), REFRUN_OFFSETS.copy()
+
+    class _Las:
+        def __init__(self, header):
+            self.header = header
+
+        def write(self, path):
+            rec["las_writes"].append(dict(path=str(path), x=np.array(self.x), y=np.array(self.y),
+                                          z=np.array(self.z), scales=np.array(self.header.scales),
+                                          offsets=np.array(self.header.offsets)))
+
+    class _Reader:
+        def __init__(self, path):
+            self.path = path
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def read(self):
+            x, y, z = registry[self.path]
+            las = _Las(_Header())
+            las.x, las.y, las.z = x, y, z
+            return las
+
+    laspy.open = lambda path, *a, **k: _Reader(path)
+    laspy.LasHeader = _Header
+    laspy.LasData = _Las
+
+    trimesh = types.ModuleType("trimesh")
+
+    class _Box:
+        def __init__(self, extents, transform):
+            self.extents, self.transform = extents, transform
+
+    class PointCloud:
+        def __init__(self, points):
+            self.points = points
+            rec["cluster_points"].append(np.array(points))
+
+        @property
+        def bounding_box_oriented(self):
+            ext, tf = oobb.bounding_box_oriented(self.points, rec["extent_order"])
+            return _Box(ext, tf)
+
+    trimesh.PointCloud = PointCloud
+
+    pandas = types.ModuleType("pandas")
+
+    class DataFrame:
+        def __init__(self, rows):
+            self.rows = rows
+
+        def to_excel(self, path, index=False):
+            rec["xlsx_rows"] = self.rows
+            rec["xlsx_path"] = str(path)
+
+    pandas.DataFrame = DataFrame
+    return {"laspy": laspy, "trimesh": trimesh, "pandas": pandas, "open3d": types.ModuleType("open3d")}
+
+
+def reference_runs(which=None):
+    """Executes /root/reference/utils/tower_extraction.py::extract_towers on the seeded cases and
+    writes tests/golden/refrun_<case>.npz.  Build container only."""
+    import importlib
+    import shutil
+    import tempfile
+    if not os.path.isdir(REF):
+        raise SystemExit("reference tree not present - reference-run fixtures can only be made in the build container")
+    for case in (which or REFRUN_CASES):
+        for order in ("unsorted", "trimesh_sorted"):
+            x, y, z, XYZ, kwargs = refrun_inputs(case)
+            registry = {"mem://" + case: (x, y, z)}
+            rec = dict(cluster_points=[], las_writes=[], xlsx_rows=[], extent_order=order)
+            saved = {k: sys.modules.get(k) for k in ("laspy", "trimesh", "pandas", "open3d")}
+            sys.modules.update(_recording_modules(registry, rec))
+            work = tempfile.mkdtemp(prefix="refrun_", dir=os.path.join(ROOT, "gpurun_out"))
+            cwd = os.getcwd()
+            sys.path.insert(0, REF)
+            logs, prog = [], []
+            try:
+                os.chdir(work)
+                te = importlib.import_module("utils.tower_extraction")
+                raised = ""
+                try:
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        towers = te.extract_towers("mem://" + case, progress_callback=prog.append,
+                                                   log_callback=logs.append, **kwargs)
+                except Exception as e:                      # the reference's own escape, recorded as such
+                    raised, towers = f"{type(e).__name__}: {e}", []
+            finally:
+                os.chdir(cwd)
+                sys.path.remove(REF)
+                for k in [m for m in sys.modules if m == "utils" or m.startswith("utils.")]:
+                    del sys.modules[k]
+                for k, v in saved.items():
+                    if v is None:
+                        sys.modules.pop(k, None)
+                    else:
+                        sys.modules[k] = v
+                shutil.rmtree(work, ignore_errors=True)
+            if order == "unsorted":
+                base = dict(rec=rec, logs=logs, prog=prog, towers=towers, raised=raised)
+                cps = rec["cluster_points"]
+                # the label vector the reference's masks imply: rebuild the filtered array with the
+                # reference's own numpy statements and locate every handed-over cluster in it
+                raw = np.stack([x, y, z], axis=1).astype(np.float32)
+                with np.errstate(all="ignore"):
+                    cen = np.mean(raw, axis=0)
+                    pts = raw - cen
+                n_f = None
+                for line in logs:
+                    if line.startswith("✅ 高度过滤完成"):
+                        n_f = int(line.split(":")[-1])
+                labels = None
+                if cps:
+                    zv = pts[:, 2]
+                    bh = np.percentile(zv, 25)
+                    filt = pts[zv > bh + 3.0]
+                    if len(filt) < 1000:
+                        filt = pts[zv > bh + 1.0]
+                    labels = np.full(len(filt), -1, np.int32)
+                    # float32 quantisation makes duplicate rows common; inside one 50 000-row chunk
+                    # identical rows always share a label, so a cluster is "every row of its chunk
+                    # whose value occurs in the handed-over array"; chunks are tried in order
+                    row_t = [("", np.float32)] * 3
+                    fv = np.ascontiguousarray(filt).view(row_t).ravel()
+                    cs, c = 50000, 0
+                    for k, cp in enumerate(cps):
+                        cv = np.ascontiguousarray(cp.astype(np.float32)).view(row_t).ravel()
+                        while True:
+                            assert c * cs < len(filt), f"cluster {k} not found in any chunk"
+                            seg = slice(c * cs, (c + 1) * cs)
+                            rows = np.flatnonzero(np.isin(fv[seg], cv) & (labels[seg] == -1)) + c * cs
+                            if len(rows) == len(cp) and np.array_equal(filt[rows], cp):
+                                break
+                            c += 1
+                        labels[rows] = k
+                    for k, cp in enumerate(cps):
+                        assert np.array_equal(filt[labels == k], cp)
+            else:
+                other = dict(towers=towers, logs=logs)
+        u, s = base, other
+        tower_fields = {}
+        for tag, tw in (("unsorted", u["towers"]), ("trimesh_sorted", s["towers"])):
+            tower_fields[f"{tag}_center"] = np.array([t["center"] for t in tw], np.float64).reshape(len(tw), 3)
+            tower_fields[f"{tag}_extent"] = np.array([t["extent"] for t in tw], np.float64).reshape(len(tw), 3)
+            tower_fields[f"{tag}_rotation"] = np.array([t["rotation"] for t in tw], np.float64).reshape(len(tw), 3, 3)
+            tower_fields[f"{tag}_north_angle"] = np.array([t["north_angle"] for t in tw], np.float64)
+            tower_fields[f"{tag}_height"] = np.array([t["height"] for t in tw], np.float64)
+            tower_fields[f"{tag}_width"] = np.array([t["width"] for t in tw], np.float64)
+            tower_fields[f"{tag}_npoints"] = np.array([len(t["points"]) for t in tw], np.int64)
+            tower_fields[f"{tag}_points_sha"] = np.array([_sha(t["points"]) for t in tw])
+        tower_fields["trimesh_sorted_logs"] = np.array(s["logs"])
+        writes = u["rec"]["las_writes"]
+        sc, of = REFRUN_SCALES, REFRUN_OFFSETS
+        np.savez_compressed(
+            os.path.join(HERE, f"refrun_{case}.npz"),
+            note="produced by executing the reference's utils/tower_extraction.py::extract_towers in the build "
+                 "container under recording modules (see gen_golden.py); numbers only",
+            case=case, n=len(x), input_sha=input_checksum(x, y, z), raised=u["raised"],
+            kwargs_json=json.dumps(kwargs), scales=sc, offsets=of,
+            logs=np.array(u["logs"]), progress=np.array(u["prog"], np.int64),
+            n_filtered_logged=-1 if n_f is None else n_f,
+            n_clusters=len(u["rec"]["cluster_points"]),
+            cluster_sizes=np.array([len(c) for c in u["rec"]["cluster_points"]], np.int64),
+            cluster_sha=np.array([_sha(c) for c in u["rec"]["cluster_points"]]),
+            labels=np.zeros(0, np.int32) if labels is None else labels.astype(np.int16 if len(u["rec"]["cluster_points"]) < 32000 else np.int32),
+            las_paths=np.array([os.path.basename(w["path"]) for w in writes]),
+            las_XYZ_sha=np.array([_sha(np.stack([np.round((w[a] - of[i]) / sc[i]).astype(np.int32)
+                                                 for i, a in enumerate("xyz")], axis=1)) for w in writes]),
+            las_xyz_f64_sha=np.array([_sha(np.stack([w["x"], w["y"], w["z"]], axis=1)) for w in writes]),
+            xlsx_ids=np.array([r["ID"] for r in u["rec"]["xlsx_rows"]]),
+            xlsx_values=np.array([[r["经度"], r["纬度"], r["海拔高度"], r["杆塔高度"], r["北方向偏角"], r["宽度"], r["长宽比"]]
+                                  for r in u["rec"]["xlsx_rows"]], np.float64).reshape(len(u["rec"]["xlsx_rows"]), 7),
+            **tower_fields)
+        print(case, "n", len(x), "filtered", n_f, "clusters", len(u["rec"]["cluster_points"]),
+              "towers", len(u["towers"]), "/", len(s["towers"]), "logs", len(u["logs"]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dbscan", "numpy", "boxes", "e2e"]
+    which = sys.argv[1:] or ["dbscan", "numpy", "boxes", "e2e", "refrun"]
     if "dbscan" in which:
         dbscan_cases()
     if "numpy" in which:
@@ -160,3 +432,5 @@ if __name__ == "__main__":
         kuangxuan_boxes()
     if "e2e" in which:
         e2e_config1()
+    if any(w == "refrun" or w.startswith("refrun:") for w in which):
+        reference_runs([w.split(":", 1)[1] for w in which if w.startswith("refrun:")] or None)

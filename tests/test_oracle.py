@@ -206,3 +206,88 @@ def test_e2e_config1_self_golden(oracle_clib):
     np.testing.assert_allclose(centres, g["trimesh_sorted_center"], rtol=0, atol=1e-3)
     true_x = (np.arange(3) + 0.5) * 100.0 / 3 + 437000.0
     np.testing.assert_allclose(np.sort(centres[:, 0]), true_x, atol=3.0)
+
+
+# ------------------------------------------------------------------ reference-run fixtures
+# tests/golden/refrun_*.npz hold what the reference's OWN extract_towers produced in the build
+# container (gen_golden.reference_runs).  The oracle must reproduce them: this is the pin that
+# ties oracle stages B0-D0 and D2-D4 to the reference's code path (utils/tower_extraction.py:57-218).
+import hashlib
+import sys
+
+sys.path.insert(0, GOLD)
+import gen_golden as gg      # noqa: E402  (inputs are rebuilt from seeds; the fixture stores their checksum)
+
+REFRUN = gg.REFRUN_CASES
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def load_refrun(case):
+    g = np.load(os.path.join(GOLD, f"refrun_{case}.npz"))
+    x, y, z, XYZ, kwargs = gg.refrun_inputs(case)
+    assert gg.input_checksum(x, y, z) == str(g["input_sha"]), "seeded input differs from the fixture's"
+    assert kwargs == json.loads(str(g["kwargs_json"]))
+    return g, x, y, z, XYZ, kwargs
+
+
+@pytest.mark.parametrize("case", REFRUN)
+def test_oracle_reproduces_reference_run(oracle_clib, case):
+    g, x, y, z, XYZ, kwargs = load_refrun(case)
+    logs = [str(s) for s in g["logs"]]
+    if case == "empty":                                   # np.percentile of nothing: filter stage gives up (:91-93)
+        assert logs[-1].startswith("⚠️ 高度过滤失败") and int(g["n_clusters"]) == 0
+        with pytest.raises(IndexError):
+            with np.errstate(all="ignore"):
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    ogf.ground_filter(np.zeros((0, 3), np.float32))
+        return
+    raw = np.stack([x, y, z], axis=1).astype(np.float32)
+    with np.errstate(all="ignore"):
+        gf = ogf.ground_filter(raw)
+    first = [ln for ln in logs if ln.startswith("✅ 高度过滤完成")][0]
+    n_first = int(first.split(":")[-1])
+    assert n_first == int(g["n_filtered_logged"])
+    if gf["used_fallback"]:
+        assert "⚠️ 过滤后点数太少，尝试降低过滤阈值" in logs and n_first < 1000
+    else:
+        assert len(gf["filtered"]) == n_first
+    if case == "nonfinite":                               # every chunk holds NaN: sklearn raises (:118-119) and the
+        assert str(g["raised"]).startswith("UnboundLocalError")   # reference's own finally clause then escapes
+        labels = odb.dbscan_chunked(gf["filtered"], 8.0, 80, 50000, fit="c")
+        assert (labels == -1).all()
+        return
+    eps, ms = kwargs.get("eps", 8.0), kwargs.get("min_points", 80)
+    labels = odb.dbscan_chunked(gf["filtered"], eps, ms, 50000, fit="c")
+    k = int(g["n_clusters"])
+    assert labels.max() + 1 == k
+    np.testing.assert_array_equal(np.bincount(labels[labels >= 0], minlength=k), g["cluster_sizes"])
+    for c in range(k):                                    # byte-for-byte what the reference handed to trimesh
+        assert _sha(gf["filtered"][labels == c]) == str(g["cluster_sha"][c])
+    np.testing.assert_array_equal(labels, g["labels"].astype(np.int32))
+    nlines = [ln for ln in logs if ln.startswith("处理分块")]
+    assert len(nlines) == -(-len(gf["filtered"]) // 50000)
+    assert f"\n=== 开始杆塔检测（候选簇：{k}个） ===" in logs
+    targs = {a: kwargs[a] for a in ("aspect_ratio_threshold", "min_height", "max_width", "min_width",
+                                    "duplicate_threshold") if a in kwargs}
+    for order in ("unsorted", "trimesh_sorted"):          # D2-D4: the reference's own accept / de-dup / angle code
+        towers, ncand = otw.towers_from_labels(gf["filtered"], labels, gf["centroid"], extent_order=order, **targs)
+        assert ncand == k and len(towers) == len(g[f"{order}_center"])
+        for i, t in enumerate(towers):
+            np.testing.assert_array_equal(t["center"], g[f"{order}_center"][i])
+            np.testing.assert_array_equal(t["extent"], g[f"{order}_extent"][i])
+            np.testing.assert_array_equal(t["rotation"], g[f"{order}_rotation"][i])
+            assert t["north_angle"] == g[f"{order}_north_angle"][i]
+            assert t["height"] == g[f"{order}_height"][i] and t["width"] == g[f"{order}_width"][i]
+            assert _sha(t["points"]) == str(g[f"{order}_points_sha"][i])
+    towers, _ = otw.towers_from_labels(gf["filtered"], labels, gf["centroid"], extent_order="unsorted", **targs)
+    assert [f"tower_{t['label']}.las" for t in towers] == [str(p) for p in g["las_paths"]]
+    sc, of = g["scales"], g["offsets"]
+    for t, want in zip(towers, g["las_XYZ_sha"]):         # coordinates the reference handed to laspy (:205,254-256)
+        orig = (t["points"] + gf["centroid"]).astype(np.float64)
+        XYZ_out = np.stack([ovx.las_unscale(orig[:, a], sc[a], of[a]) for a in range(3)], axis=1)
+        assert _sha(XYZ_out) == str(want)
