@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tile-stream", action="store_true",
                     help="skip the two-tiles-in-flight side measurement (profiling runs)")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip every side measurement (voxel stage, other workloads): profiling runs")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -198,10 +200,11 @@ def main():
     tr_path = os.path.join(ROOT, "profiles", "traffic.json")   # PMC passes, see profiles/README.md
     if os.path.exists(tr_path):
         try:
-            tr = json.load(open(tr_path))
-            for r in (roofline, knn, stream):
-                if r and tr.get("points") == N and r["kernel"] in tr.get("kernels", {}):
+            tr = json.load(open(tr_path)).get("workloads", {}).get(f"{args.kind}/{args.frame}/{N}")
+            for r in (roofline, knn, stream):     # counters of the SAME workload (kind / frame / points) only
+                if r and tr and r["kernel"] in tr.get("kernels", {}):
                     r["traffic"] = tr["kernels"][r["kernel"]]
+                    r["traffic_source"] = f"profiles/{tr.get('source')}_pmc_traffic.csv"
         except Exception:
             pass
 
@@ -228,7 +231,7 @@ def main():
     }
 
     # ---- BASELINE config 2 side measurement: the voxel stage on 10 M float64 points (not in `value`)
-    if world == 1:
+    if world == 1 and not args.no_side:
         try:
             nv = 10_000_000
             xyz64 = synth.corridor_torch(nv, seed=synth.SEED0 + 1, kind="corridor", offset=True, device=dev)

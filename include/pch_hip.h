@@ -11,7 +11,10 @@
  *  - plain C: pointers, sizes, scalars.  No torch/HIP types in signatures
  *    (`stream` is a hipStream_t passed as void*; NULL = default stream).
  *  - every `const T*` / `T*` argument is a DEVICE pointer unless its name ends in
- *    `_host`.  Buffers are caller-owned.
+ *    `_host`.  Buffers are caller-owned.  Every entry point looks up the device that owns
+ *    its first buffer (hipPointerGetAttributes), makes it current for the call
+ *    (hipSetDevice) and restores the caller's device on return; a host pointer where a
+ *    device pointer is expected gives PCH_ERR_ARG.
  *  - return value: 0 = ok, <0 = PCH_ERR_*.  pch_last_error() gives a thread-local text.
  *  - the library never allocates device memory: scratch is a caller-provided workspace
  *    whose size comes from the matching *_ws_bytes() (a pure host function).
@@ -31,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PCH_VERSION 100
+#define PCH_VERSION 200
 
 #define PCH_OK               0
 #define PCH_ERR_ARG         -1   /* bad argument (null pointer, negative size, eps<=0 ...) */
@@ -114,7 +117,8 @@ int pch_percentile_f32(const float* base, int64_t n, int64_t stride, const float
  * out_points   [n,3] float32 capacity; first *out_count rows = points[keep] (file order)
  * out_index    [n]   int32 (may be NULL): original row of each kept point
  * out_scalars  [8]   float32: centroid xyz, base, threshold, used_fallback(0/1),
- *                    (float)count kept at `offset` (exact below 2^24), 0
+ *                    [6] = the BITS of the uint32 count kept at `offset` (an integer in a
+ *                    float slot - reinterpret, do not convert), [7] = 0
  * out_count    [1]   int64
  * out_aabb     [6]   float32 (may be NULL): min xyz, max xyz of the kept points
  */
@@ -143,12 +147,22 @@ int pch_ground_filter_f32(const float* raw, int64_t n, double pct, float offset,
  * border point -> smallest cluster id among its core neighbours.
  * Synchronises once (reads the bounding box to size the cell grid) unless aabb_host
  * (min xyz, max xyz of the input, any superset box) is given.
+ * Cell sort: one workgroup per chunk or one global radix sort, chosen by the chunk count;
+ * environment PCH_DBSCAN_SORT=chunk|global (read once per process) or
+ * pch_dbscan_set_sort_mode(0 auto | 1 chunk | 2 global) force one - same results either way.
  */
+void   pch_dbscan_set_sort_mode(int mode);
 size_t pch_dbscan_ws_bytes(int64_t n);
 int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t min_samples,
                    int64_t chunk_size, const float* aabb_host,
                    int32_t* labels, uint8_t* core, int32_t* out_nclusters,
                    void* ws, size_t ws_bytes, void* stream);
+
+/* First row of xyz [n,3] float32 that holds NaN or +-inf, -1 if every row is finite.
+ * Replaces: sklearn's input validation inside DBSCAN.fit (check_array, ensure_all_finite), which
+ * is what makes a chunk "fail" in the reference (utils/tower_extraction.py:107-119).
+ * out_row [1] int64 (device). */
+int pch_first_nonfinite_row_f32(const float* xyz, int64_t n, int64_t* out_row, void* stream);
 
 /* ------------------------------------------------------------------ stage D0
  * Groups points by cluster label in one pass instead of the reference's K boolean

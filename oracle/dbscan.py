@@ -180,6 +180,12 @@ def dbscan_chunked(filtered_points, eps=8.0, min_samples=80, chunk_size=50000, f
     cs = int(chunk_size) if int(chunk_size) > 0 else max(n, 1)
     for start in range(0, n, cs):
         chunk = pts[start:start + cs]
+        if not np.isfinite(chunk).all():
+            # DBSCAN.fit validates its input first (sklearn check_array, ensure_all_finite) and raises
+            # ValueError for NaN/inf; the reference's except clause (:118-119) leaves the chunk at -1
+            # and current_label untouched.  (Its finally clause then escapes with UnboundLocalError -
+            # tests/golden/refrun_nonfinite.npz - so this is the labelling its except clause intends.)
+            continue
         chunk_labels = np.asarray(f(chunk, eps, min_samples)[0]).copy()
         chunk_labels[chunk_labels != -1] += current_label             # :114
         all_labels[start:start + cs] = chunk_labels                   # :115

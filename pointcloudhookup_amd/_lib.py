@@ -43,6 +43,8 @@ _SIGS = {
     "pch_ground_filter_ws_bytes": (_sz, [_i64]),
     "pch_ground_filter_f32": (C.c_int, [_vp, _i64, _f64, _f32, _f32, _i64, _vp, _vp, _vp, _vp, _vp,
                                         _vp, _sz, _vp]),
+    "pch_dbscan_set_sort_mode": (None, [C.c_int]),
+    "pch_first_nonfinite_row_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pch_dbscan_ws_bytes": (_sz, [_i64]),
     "pch_dbscan_f32": (C.c_int, [_vp, _i64, _f64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pch_segment_by_label_ws_bytes": (_sz, [_i64, _i32]),

@@ -37,6 +37,25 @@ void set_error(const char* fmt, ...);
         }                                                        \
     } while (0)
 
+// ---------------------------------------------------------------- device guard
+// Every entry point runs on the device that owns its buffers, whatever device is current in the
+// calling thread: the guard looks the pointer up (hipPointerGetAttributes), switches with
+// hipSetDevice and restores the caller's device on exit.  `rc` is PCH_OK, PCH_ERR_ARG (host
+// pointer) or PCH_ERR_HIP.
+constexpr int PCH_MAX_DEVICES = 16;
+struct DeviceGuard {
+    int rc, prev, dev;
+    explicit DeviceGuard(const void* device_ptr);
+    ~DeviceGuard();
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+// device the calling thread currently has selected, clamped to [0, PCH_MAX_DEVICES)
+int current_device_slot();
+#define PCH_DEVICE_GUARD(ptr)                 \
+    ::pch::DeviceGuard _pch_guard(ptr);       \
+    if (_pch_guard.rc != PCH_OK) return _pch_guard.rc
+
 // ---------------------------------------------------------------- workspace arena
 // The same plan function is run once with base == nullptr (size query) and once with the
 // caller's buffer, so *_ws_bytes() can never disagree with the real carve-up.
@@ -62,7 +81,7 @@ struct Arena {
 
 // ---------------------------------------------------------------- small device -> host reads
 // A few words the host needs to size the next launch, without draining the stream: the copy lands
-// in a pinned per-thread buffer and the host waits for an event recorded right behind it, so
+// in a pinned per-thread, per-device buffer and the host waits for an event recorded right behind it, so
 // kernels enqueued after the copy keep the GPU busy meanwhile.  (pch_core.hip)
 struct HostPeek {
     void*      pinned;          // 256 bytes of pinned host memory
@@ -82,7 +101,6 @@ int dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples, int
 
 // ---------------------------------------------------------------- profiling
 // When enabled every PCH_LAUNCH is bracketed by hipEvents recorded on the launch stream.
-void prof_begin_call();                       // (records accumulate until collected)
 bool prof_enabled();
 bool prof_wanted(const char* name);             // name filter (pch_set_profiling_filter)
 void prof_pre(const char* name, hipStream_t s);

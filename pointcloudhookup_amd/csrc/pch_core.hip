@@ -19,15 +19,57 @@ void set_error(const char* fmt, ...) {
 struct ProfRec {
     const char* name;
     hipEvent_t  e0, e1;
+    int         slot;          // device the events belong to
 };
 static thread_local bool                 g_prof_on = false;
 static thread_local std::vector<ProfRec> g_recs;
-static thread_local std::vector<hipEvent_t> g_pool;
+// HIP objects belong to the device that was current when they were made: the per-thread caches
+// below are kept per device (a thread may serve several GPUs) and are destroyed at thread exit.
+struct EventPools {
+    std::vector<hipEvent_t> pool[PCH_MAX_DEVICES];
+    ~EventPools() {
+        for (auto& p : pool)
+            for (hipEvent_t e : p) (void)hipEventDestroy(e);
+    }
+};
+static thread_local EventPools g_pools;
 
-static hipEvent_t take_event() {
-    if (!g_pool.empty()) {
-        hipEvent_t e = g_pool.back();
-        g_pool.pop_back();
+int current_device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+    return d < PCH_MAX_DEVICES ? d : PCH_MAX_DEVICES - 1;
+}
+
+DeviceGuard::DeviceGuard(const void* device_ptr) : rc(PCH_OK), prev(-1), dev(-1) {
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; }
+    if (!device_ptr) { dev = prev; return; }            // nothing to look up (argument checks report the null)
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, device_ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("not a device pointer (hipPointerGetAttributes failed)");
+        rc = PCH_ERR_ARG;
+        return;
+    }
+    if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged) {
+        set_error("expected a device pointer, got host memory");
+        rc = PCH_ERR_ARG;
+        return;
+    }
+    dev = at.device;
+    if (dev != prev && hipSetDevice(dev) != hipSuccess) {
+        set_error("hipSetDevice(%d) failed", dev);
+        rc = PCH_ERR_HIP;
+    }
+}
+DeviceGuard::~DeviceGuard() {
+    if (prev >= 0 && dev >= 0 && dev != prev) (void)hipSetDevice(prev);
+}
+
+static hipEvent_t take_event(int slot) {
+    auto& pool = g_pools.pool[slot];
+    if (!pool.empty()) {
+        hipEvent_t e = pool.back();
+        pool.pop_back();
         return e;
     }
     hipEvent_t e = nullptr;
@@ -39,8 +81,6 @@ static hipEvent_t take_event() {
 // Records accumulate over pch_* calls until pch_get_profile() collects them (bench.py reads
 // one whole step at once); a cap keeps a caller that never collects from growing forever.
 constexpr size_t PROF_MAX_RECORDS = 16384;
-
-void prof_begin_call() {}
 
 static thread_local std::vector<std::string> g_filter;   // empty: every kernel
 
@@ -55,8 +95,8 @@ bool prof_wanted(const char* name) {
 
 static void prof_clear() {
     for (auto& r : g_recs) {
-        g_pool.push_back(r.e0);
-        g_pool.push_back(r.e1);
+        g_pools.pool[r.slot].push_back(r.e0);
+        g_pools.pool[r.slot].push_back(r.e1);
     }
     g_recs.clear();
 }
@@ -64,16 +104,26 @@ static void prof_clear() {
 void prof_pre(const char* name, hipStream_t s) {
     ProfRec r;
     r.name = name;
-    r.e0 = take_event();
-    r.e1 = take_event();
+    r.slot = current_device_slot();
+    r.e0 = take_event(r.slot);
+    r.e1 = take_event(r.slot);
     (void)hipEventRecord(r.e0, s);
     g_recs.push_back(r);
 }
 
 void prof_post(hipStream_t s) { (void)hipEventRecord(g_recs.back().e1, s); }
 
+struct HostPeeks {
+    HostPeek hp[PCH_MAX_DEVICES];
+    HostPeeks() { for (auto& h : hp) h = {nullptr, nullptr, false}; }
+    ~HostPeeks() {
+        for (auto& h : hp)
+            if (h.ok) { (void)hipEventDestroy(h.ev); (void)hipHostFree(h.pinned); }
+    }
+};
 HostPeek& host_peek() {
-    static thread_local HostPeek hp = {nullptr, nullptr, false};
+    static thread_local HostPeeks all;
+    HostPeek& hp = all.hp[current_device_slot()];
     if (!hp.ok) {
         if (hipHostMalloc(&hp.pinned, 256, hipHostMallocDefault) == hipSuccess &&
             hipEventCreateWithFlags(&hp.ev, hipEventDisableTiming) == hipSuccess)

@@ -96,8 +96,9 @@ __device__ __forceinline__ double db_boxbox_d2(const float* __restrict__ a, cons
     return d;
 }
 
-// ---- chunks that contain NaN/inf: sklearn raises for such a chunk and the reference leaves it
-// at -1 (utils/tower_extraction.py:118-119); its points are parked in an extra "trash" chunk
+// ---- chunks that contain NaN/inf: sklearn raises for such a chunk (utils/tower_extraction.py:118-119);
+// its rows keep their own chunk key and sit in ONE cell (0,0,0) of that chunk that is never core, so
+// every chunk owns at least one cell and chunk_cells[] is complete (db_cells_k)
 __global__ __launch_bounds__(DB_THREADS) void db_chunkbad_k(const float* __restrict__ xyz, int64_t n,
                                                             int64_t chunk_size, uint32_t* __restrict__ bad) {
     for (int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x; i < n;
@@ -107,6 +108,22 @@ __global__ __launch_bounds__(DB_THREADS) void db_chunkbad_k(const float* __restr
         const uint32_t c = __float_as_uint(xyz[3 * i + 2]) & 0x7FFFFFFFu;
         if (a >= 0x7F800000u || b >= 0x7F800000u || c >= 0x7F800000u) atomicOr(&bad[i / chunk_size], 1u);
     }
+}
+
+// ---- first row holding NaN/inf (what sklearn's check_array rejects before DBSCAN.fit starts) ----
+__global__ __launch_bounds__(DB_THREADS) void db_first_bad_k(const float* __restrict__ xyz, int64_t n,
+                                                             unsigned long long* __restrict__ first) {
+    unsigned long long best = ~0ull;
+    for (int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * DB_THREADS) {
+        const uint32_t a = __float_as_uint(xyz[3 * i + 0]) & 0x7FFFFFFFu;
+        const uint32_t b = __float_as_uint(xyz[3 * i + 1]) & 0x7FFFFFFFu;
+        const uint32_t c = __float_as_uint(xyz[3 * i + 2]) & 0x7FFFFFFFu;
+        if ((a >= 0x7F800000u || b >= 0x7F800000u || c >= 0x7F800000u) && (unsigned long long)i < best)
+            best = (unsigned long long)i;
+    }
+    best = wave_reduce_min(best);
+    if (lane_id() == 0 && best != ~0ull) atomicMin(first, best);
 }
 
 // ---- bounding box of the finite input points (only when the caller did not provide one) ------
@@ -1231,6 +1248,19 @@ static void db_plan(Arena& a, int64_t n, DbWs& w) {
     w.rowtab = a.take<int2>((size_t)w.rowtab_cells * DB_ROWS);
 }
 
+// PCH_DBSCAN_SORT (chunk | global), read once per process unless pch_dbscan_set_sort_mode() overrides it:
+// 0 automatic, 1 chunk-local, 2 global
+static int g_sort_mode = -1;
+static int db_sort_mode() {
+    int m = __atomic_load_n(&g_sort_mode, __ATOMIC_RELAXED);
+    if (m < 0) {
+        const char* e = getenv("PCH_DBSCAN_SORT");
+        m = (e && strcmp(e, "chunk") == 0) ? 1 : (e && strcmp(e, "global") == 0) ? 2 : 0;
+        __atomic_store_n(&g_sort_mode, m, __ATOMIC_RELAXED);
+    }
+    return m;
+}
+
 // host mirror of f32_unordered
 static float host_unordered(uint32_t k) {
     uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
@@ -1243,6 +1273,23 @@ static float host_unordered(uint32_t k) {
 
 using namespace pch;
 
+extern "C" int pch_first_nonfinite_row_f32(const float* xyz, int64_t n, int64_t* out_row, void* stream) {
+    PCH_DEVICE_GUARD(out_row);
+    hipStream_t s = (hipStream_t)stream;
+    PCH_REQUIRE(n >= 0 && out_row && (n == 0 || xyz), "bad argument");
+    PCH_HIP_TRY(hipMemsetAsync(out_row, 0xFF, sizeof(int64_t), s));             // -1: every row finite
+    if (n == 0) return PCH_OK;
+    int64_t gb = ceil_div(n, DB_THREADS * 8);
+    if (gb > 2048) gb = 2048;
+    PCH_LAUNCH("db_first_bad", db_first_bad_k, dim3((unsigned)gb), dim3(DB_THREADS), 0, s, xyz, n,
+               reinterpret_cast<unsigned long long*>(out_row));
+    return PCH_OK;
+}
+
+extern "C" void pch_dbscan_set_sort_mode(int mode) {
+    __atomic_store_n(&g_sort_mode, (mode == 1 || mode == 2) ? mode : 0, __ATOMIC_RELAXED);
+}
+
 extern "C" size_t pch_dbscan_ws_bytes(int64_t n) {
     if (n < 0) return 0;
     Arena a;
@@ -1254,7 +1301,6 @@ extern "C" size_t pch_dbscan_ws_bytes(int64_t n) {
 int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples, int64_t chunk_size,
                     const float* aabb_host, int32_t* labels, uint8_t* core, int32_t* out_nclusters, void* ws,
                     size_t ws_bytes, hipStream_t s, int32_t* k_host) {
-    prof_begin_call();
     if (k_host) *k_host = 0;
     PCH_REQUIRE(n >= 0 && n < (int64_t(1) << 31), "n out of range [0, 2^31)");
     PCH_REQUIRE(eps > 0.0, "eps must be > 0 (sklearn: InvalidParameterError)");
@@ -1333,9 +1379,9 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
     const uint64_t* ks;
     // One workgroup per chunk only pays with enough chunks to fill the GPU (measured break-even near
     // 100 chunks of 50 000 rows); PCH_DBSCAN_SORT=chunk / global forces a path (tests compare them)
-    const char* sort_mode = getenv("PCH_DBSCAN_SORT");
-    const bool force_global = sort_mode && strcmp(sort_mode, "global") == 0;
-    const bool force_chunk = sort_mode && strcmp(sort_mode, "chunk") == 0;
+    const int sort_mode = db_sort_mode();
+    const bool force_global = sort_mode == 2;
+    const bool force_chunk = sort_mode == 1;
     if (cellbits <= 32 && chunk_size <= CS_MAX_CHUNK && !force_global && (force_chunk || nchunks >= CS_MIN_CHUNKS)) {
         // chunk-local path: one workgroup per chunk builds keys, sorts and gathers
         const int passes = cellbits <= 0 ? 0 : (cellbits + 7) / 8;
@@ -1368,6 +1414,9 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
     // the cell count sizes the next grids: fetch it while db_cells_k (sized by n) runs
     uint32_t st_m[2];
     PCH_TRY(peek_enqueue(w.meta + 6, sizeof(st_m), s));
+    // chunk_cells is written at the first cell of every chunk; the memset makes a chunk without a cell
+    // (cannot happen today: NaN/inf chunks keep a cell of their own) an empty range instead of garbage
+    PCH_HIP_TRY(hipMemsetAsync(w.chunk_cells, 0, sizeof(uint32_t) * (size_t)(nchunks + 1), s));
     PCH_LAUNCH("db_cells", db_cells_k, dim3(gn), dim3(DB_THREADS), 0, s, ks, (const uint32_t*)w.head, n,
                cellbits, nchunks, w.cid, w.cell_start, w.cell_key, w.chunk_cells);
     PCH_TRY(peek_wait(st_m, sizeof(st_m)));
@@ -1429,6 +1478,7 @@ extern "C" int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t m
                               int64_t chunk_size, const float* aabb_host, int32_t* labels,
                               uint8_t* core, int32_t* out_nclusters, void* ws, size_t ws_bytes,
                               void* stream) {
+    PCH_DEVICE_GUARD(xyz ? (const void*)xyz : (const void*)out_nclusters);
     return dbscan_run(xyz, n, eps, min_samples, chunk_size, aabb_host, labels, core, out_nclusters, ws, ws_bytes,
                       (hipStream_t)stream, nullptr);
 }

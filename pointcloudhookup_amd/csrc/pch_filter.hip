@@ -3,6 +3,7 @@
 // Reference: utils/tower_extraction.py:62-64 (centroid, centring), :82-89 (percentile filter).
 #include "pch_prims.h"
 #include "pch_mean.h"
+#include "pch_lookback.h"
 
 namespace pch {
 
@@ -282,8 +283,17 @@ static int select_percentile(const float* base, int64_t n, int64_t stride, const
 // per-thread side stream + events: the select passes only need the raw z column, so they run
 // beside the (latency-bound, 3-wave) centroid walk
 struct SideStream { hipStream_t s; hipEvent_t ev_fork, ev_join; bool ok; };
+struct SideStreams {                                    // one per device this thread has used; gone with the thread
+    SideStream ss[PCH_MAX_DEVICES];
+    SideStreams() { for (auto& x : ss) x = {nullptr, nullptr, nullptr, false}; }
+    ~SideStreams() {
+        for (auto& x : ss)
+            if (x.ok) { (void)hipEventDestroy(x.ev_fork); (void)hipEventDestroy(x.ev_join); (void)hipStreamDestroy(x.s); }
+    }
+};
 static SideStream& side_stream() {
-    static thread_local SideStream ss = {nullptr, nullptr, nullptr, false};
+    static thread_local SideStreams all;
+    SideStream& ss = all.ss[current_device_slot()];
     if (!ss.ok) {
         if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&ss.ev_fork, hipEventDisableTiming) == hipSuccess &&
@@ -306,60 +316,17 @@ static SideStream& side_stream() {
 constexpr int GF_THREADS = 256;
 constexpr int GF_ROUNDS  = 64;
 constexpr int GF_TILE    = GF_THREADS * GF_ROUNDS;   // 16 384 points per workgroup: few enough tiles for the look-back
-constexpr int GF_LOOK    = 4;                        // 64-tile windows fetched per look-back round trip
 constexpr int GF_SLOTS   = 64;
 
 struct GfState {
     uint32_t total[2];                     // kept with threshold A (offset) / B (fallback)
     uint32_t use_b;
     uint32_t pad;
+    uint32_t ticket[2];                    // next logical tile of either sweep (order of arrival, see gf_compact_k)
+    uint32_t pad2[2];
     uint32_t slots[2][GF_SLOTS][6];        // per sweep: ~min xyz (complemented) / max xyz as ordered uint32,
                                            // all folded with atomicMax so that 0 is the neutral start
 };
-
-constexpr uint64_t GF_FLAG_AGG = 1ull << 62, GF_FLAG_INCL = 2ull << 62;
-
-// exclusive prefix of tile b (wave 0 of the workgroup, all 64 lanes); T = this tile's count
-__device__ __forceinline__ uint32_t gf_lookback(uint64_t* __restrict__ status, int64_t b, uint32_t T) {
-    const int l = lane_id();
-    if (b == 0) {
-        if (l == 0) __hip_atomic_store(&status[0], GF_FLAG_INCL | T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0;
-    }
-    if (l == 0) __hip_atomic_store(&status[b], GF_FLAG_AGG | T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t excl = 0;
-    bool done = false;
-    for (int64_t j = b - 1; !done; j -= 64 * GF_LOOK) {  // windows [j-64k-63, j-64k]: lane l looks at tile j-64k-l
-        uint64_t v[GF_LOOK];
-        do {                                            // tiles in front were dispatched earlier: they publish
-            bool missing = false;
-#pragma unroll
-            for (int k = 0; k < GF_LOOK; ++k) {
-                const int64_t idx = j - 64 * k - l;
-                v[k] = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                : GF_FLAG_INCL;         // in front of tile 0: prefix 0
-                missing |= (v[k] >> 62) == 0;
-            }
-            if (__ballot(missing) == 0) break;
-            __builtin_amdgcn_s_sleep(1);
-        } while (true);
-#pragma unroll
-        for (int k = 0; k < GF_LOOK; ++k) {
-            if (done) break;
-            const unsigned long long incl = __ballot((v[k] >> 62) == 2);
-            if (incl) {                                 // nearest tile with a full prefix ends the walk
-                const int first = (int)__builtin_ctzll(incl);
-                excl += wave_reduce_add(l <= first ? (uint32_t)v[k] : 0u);
-                done = true;
-            } else {
-                excl += wave_reduce_add((uint32_t)v[k]);
-            }
-        }
-    }
-    if (l == 0) __hip_atomic_store(&status[b], GF_FLAG_INCL | (uint64_t)(excl + T), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-    return excl;
-}
 
 template <int WHICH>
 __global__ __launch_bounds__(GF_THREADS) void gf_compact_k(
@@ -371,11 +338,20 @@ __global__ __launch_bounds__(GF_THREADS) void gf_compact_k(
     __shared__ uint32_t excl_sh;
     __shared__ uint32_t box[GF_THREADS / 64][6];
     __shared__ unsigned long long masks[GF_THREADS / 64][GF_ROUNDS];      // survivors of every 64-point round
+    __shared__ uint32_t tile_sh;
     if (WHICH == 1 && st->use_b == 0) return;
+    // The look-back below waits for every tile in front of this one, so the tile order must be an
+    // order in which workgroups START: HIP promises nothing about blockIdx dispatch order, and a
+    // resident workgroup spinning on a tile that was never scheduled would hang the GPU.  The logical
+    // tile is therefore a ticket drawn on arrival (as rocPRIM's look-back scan does): every tile with
+    // a smaller ticket belongs to a workgroup that is already running.
+    if (threadIdx.x == 0) tile_sh = atomicAdd(&st->ticket[WHICH], 1u);
+    __syncthreads();
+    const int64_t tile = tile_sh;
     const float cx = centroid[0], cy = centroid[1], cz = centroid[2];
     const float thr = scal[1 + WHICH];
     const int w = wave_id(), l = lane_id();
-    const int64_t seg = (int64_t)blockIdx.x * GF_TILE + (int64_t)w * (64 * GF_ROUNDS);
+    const int64_t seg = tile * GF_TILE + (int64_t)w * (64 * GF_ROUNDS);
     // ---- sweep over the z column: survivor masks and the tile's count
     uint32_t run = 0;
 #pragma unroll 8
@@ -391,10 +367,10 @@ __global__ __launch_bounds__(GF_THREADS) void gf_compact_k(
     __syncthreads();
     const uint32_t T = wtot[0] + wtot[1] + wtot[2] + wtot[3];
     if (w == 0) {
-        const uint32_t e = gf_lookback(status, blockIdx.x, T);
+        const uint32_t e = gf_lookback(status, tile, T);
         if (l == 0) {
             excl_sh = e;
-            if (blockIdx.x == gridDim.x - 1) {                // the last tile knows the total: it also decides
+            if (tile == (int64_t)gridDim.x - 1) {                // the last tile knows the total: it also decides
                 st->total[WHICH] = e + T;                     // whether the fallback threshold applies
                 if (WHICH == 0) st->use_b = ((long long)(e + T) < min_keep) ? 1u : 0u;
             }
@@ -442,7 +418,7 @@ __global__ __launch_bounds__(GF_THREADS) void gf_compact_k(
         const int a = threadIdx.x;
         uint32_t v = box[0][a];
         for (int w2 = 1; w2 < GF_THREADS / 64; ++w2) v = box[w2][a] > v ? box[w2][a] : v;
-        if (v) atomicMax(&st->slots[WHICH][blockIdx.x % GF_SLOTS][a], v);
+        if (v) atomicMax(&st->slots[WHICH][tile % GF_SLOTS][a], v);
     }
 }
 
@@ -459,7 +435,7 @@ __global__ void gf_finalize_k(const GfState* __restrict__ st, const float* __res
         out_scalars[3] = scal[0];
         out_scalars[4] = scal[1 + use_b];
         out_scalars[5] = use_b ? 1.0f : 0.0f;
-        out_scalars[6] = (float)st->total[0];     // kept at the first threshold (exact below 2^24)
+        out_scalars[6] = __uint_as_float(st->total[0]);   // kept at the first threshold: the uint32 count's BITS
         out_scalars[7] = 0.0f;
         *out_count = (int64_t)st->total[use_b];
     }
@@ -506,7 +482,7 @@ extern "C" size_t pch_mean_seq_f32_ws_bytes(int64_t n) {
 
 extern "C" int pch_mean_seq_f32(const float* xyz, int64_t n, float* out_centroid, void* ws,
                                 size_t ws_bytes, void* stream) {
-    prof_begin_call();
+    PCH_DEVICE_GUARD(xyz ? (const void*)xyz : (const void*)out_centroid);
     PCH_REQUIRE(n >= 0 && out_centroid && ws, "bad argument");
     PCH_REQUIRE(n == 0 || xyz, "null input");
     Arena a(ws, ws_bytes);
@@ -517,7 +493,7 @@ extern "C" int pch_mean_seq_f32(const float* xyz, int64_t n, float* out_centroid
 }
 
 extern "C" int pch_mean_seq_serial_f32(const float* xyz, int64_t n, float* out_centroid, void* stream) {
-    prof_begin_call();
+    PCH_DEVICE_GUARD(xyz ? (const void*)xyz : (const void*)out_centroid);
     PCH_REQUIRE(n >= 0 && out_centroid, "bad argument");
     PCH_REQUIRE(n == 0 || xyz, "null input");
     return mean_seq_serial_launch(xyz, n, out_centroid, (hipStream_t)stream);
@@ -533,7 +509,7 @@ extern "C" size_t pch_percentile_f32_ws_bytes(int64_t) {
 extern "C" int pch_percentile_f32(const float* base, int64_t n, int64_t stride, const float* sub,
                                   double q_percent, float* out, void* ws, size_t ws_bytes,
                                   void* stream) {
-    prof_begin_call();
+    PCH_DEVICE_GUARD(base);
     hipStream_t s = (hipStream_t)stream;
     PCH_REQUIRE(n >= 1, "percentile of an empty array (numpy raises IndexError)");
     PCH_REQUIRE(base && out && ws && stride >= 1, "bad argument");
@@ -559,7 +535,7 @@ extern "C" int pch_ground_filter_f32(const float* raw, int64_t n, double pct, fl
                                      float fallback_offset, int64_t min_keep, float* out_points,
                                      int32_t* out_index, float* out_scalars, int64_t* out_count,
                                      float* out_aabb, void* ws, size_t ws_bytes, void* stream) {
-    prof_begin_call();
+    PCH_DEVICE_GUARD(raw);
     hipStream_t s = (hipStream_t)stream;
     PCH_REQUIRE(n >= 1 && n < (int64_t(1) << 31), "n out of range [1, 2^31) (numpy raises on empty input)");
     PCH_REQUIRE(raw && out_points && out_scalars && out_count && ws, "null buffer");

@@ -1,0 +1,56 @@
+// Decoupled look-back over an ordered sequence of tiles (single-pass prefix sum across workgroups).
+#pragma once
+#include "pch_common.h"
+
+namespace pch {
+
+constexpr int GF_LOOK = 4;                        // 64-tile windows fetched per look-back round trip
+constexpr uint64_t GF_FLAG_AGG = 1ull << 62, GF_FLAG_INCL = 2ull << 62;
+
+// Exclusive prefix of tile b (called by ONE whole wave, all 64 lanes); T = this tile's count.
+// status: one zeroed 64-bit word per tile (2-bit flag + 32-bit value, one relaxed agent-scope atomic).
+// FORWARD PROGRESS: the caller waits for every tile in front of b, so b must be an order in which
+// workgroups START (a ticket drawn on arrival), never blockIdx - HIP promises no dispatch order.
+__device__ __forceinline__ uint32_t gf_lookback(uint64_t* __restrict__ status, int64_t b, uint32_t T) {
+    const int l = lane_id();
+    if (b == 0) {
+        if (l == 0) __hip_atomic_store(&status[0], GF_FLAG_INCL | T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    if (l == 0) __hip_atomic_store(&status[b], GF_FLAG_AGG | T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0;
+    bool done = false;
+    for (int64_t j = b - 1; !done; j -= 64 * GF_LOOK) {  // windows [j-64k-63, j-64k]: lane l looks at tile j-64k-l
+        uint64_t v[GF_LOOK];
+        do {                                            // tiles in front drew their ticket earlier: they run and publish
+            bool missing = false;
+#pragma unroll
+            for (int k = 0; k < GF_LOOK; ++k) {
+                const int64_t idx = j - 64 * k - l;
+                v[k] = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : GF_FLAG_INCL;         // in front of tile 0: prefix 0
+                missing |= (v[k] >> 62) == 0;
+            }
+            if (__ballot(missing) == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        } while (true);
+#pragma unroll
+        for (int k = 0; k < GF_LOOK; ++k) {
+            if (done) break;
+            const unsigned long long incl = __ballot((v[k] >> 62) == 2);
+            if (incl) {                                 // nearest tile with a full prefix ends the walk
+                const int first = (int)__builtin_ctzll(incl);
+                excl += wave_reduce_add(l <= first ? (uint32_t)v[k] : 0u);
+                done = true;
+            } else {
+                excl += wave_reduce_add((uint32_t)v[k]);
+            }
+        }
+    }
+    if (l == 0) __hip_atomic_store(&status[b], GF_FLAG_INCL | (uint64_t)(excl + T), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+
+}  // namespace pch

@@ -42,6 +42,7 @@ extern "C" int pch_tower_clusters_f32(const float* raw, int64_t n, double pct, f
                                       int32_t k_cap, PchTowerClusters* info_host, void* ws,
                                       size_t ws_bytes, void* stream) {
     hipStream_t s = (hipStream_t)stream;
+    PCH_DEVICE_GUARD(raw);
     PCH_REQUIRE(info_host != nullptr, "info_host is null");
     memset(info_host, 0, sizeof(*info_host));
     PCH_REQUIRE(ws != nullptr && nf_cap >= 0 && k_cap >= 0, "bad argument");
@@ -65,7 +66,11 @@ extern "C" int pch_tower_clusters_f32(const float* raw, int64_t n, double pct, f
     info_host->base = h.scalars[3];
     info_host->threshold = h.scalars[4];
     info_host->used_fallback = h.scalars[5] != 0.0f;
-    info_host->count_at_offset = (int64_t)h.scalars[6];
+    {
+        uint32_t c0;
+        memcpy(&c0, &h.scalars[6], sizeof(c0));          // integer count in the float slot's bits
+        info_host->count_at_offset = (int64_t)c0;
+    }
     memcpy(info_host->aabb, h.aabb, sizeof(h.aabb));
     info_host->count = h.count;
     const int64_t nf = h.count;

@@ -253,7 +253,7 @@ extern "C" size_t pch_segment_by_label_ws_bytes(int64_t n, int32_t nclusters) {
 extern "C" int pch_segment_by_label(const int32_t* labels, const float* xyz, int64_t n,
                                     int32_t nclusters, int32_t* out_perm, int64_t* out_offsets,
                                     float* out_stats, void* ws, size_t ws_bytes, void* stream) {
-    prof_begin_call();
+    PCH_DEVICE_GUARD(labels ? (const void*)labels : (const void*)out_offsets);
     hipStream_t s = (hipStream_t)stream;
     PCH_REQUIRE(n >= 0 && n < (int64_t(1) << 31) && nclusters >= 0, "bad size");
     PCH_REQUIRE(out_offsets != nullptr, "out_offsets is null");

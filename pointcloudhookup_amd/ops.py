@@ -200,7 +200,7 @@ def ground_filter(raw, pct=25.0, offset=3.0, fallback_offset=1.0, min_keep=1000,
         nf = int(host[16:18].view("<i8")[0])
     return dict(points=out_points[:nf], index=None if out_index is None else out_index[:nf],
                 centroid=host[0:3].copy(), base=host[3], threshold=host[4],
-                used_fallback=bool(host[5] != 0.0), count_at_offset=int(host[6]),
+                used_fallback=bool(host[5] != 0.0), count_at_offset=int(host[6:7].view("<u4")[0]),
                 aabb=host[8:14].copy(), count=nf)
 
 
@@ -227,6 +227,23 @@ def dbscan(xyz, eps=8.0, min_samples=80, chunk_size=50000, aabb=None, want_core=
                                     _ptr(core), _ptr(ncl), _ptr(ws), ws.numel(), _stream()))
         k = int(ncl.item())
     return labels, core, k
+
+
+def set_dbscan_sort_mode(mode):
+    """Cell sort of ops.dbscan: "auto" (by chunk count), "chunk" (one workgroup per chunk) or "global"
+    (one radix sort).  Same results either way; tests compare them."""
+    _lib.lib().pch_dbscan_set_sort_mode({"auto": 0, "chunk": 1, "global": 2}[mode])
+
+
+def first_nonfinite_row(xyz):
+    """Index of the first row of float32 [n,3] holding NaN/inf, -1 if none (what makes sklearn's
+    DBSCAN.fit reject a chunk).  Synchronises."""
+    L = _lib.lib()
+    xyz = _need_cuda(xyz, torch.float32, "xyz").reshape(-1, 3)
+    out = torch.empty((1,), dtype=torch.int64, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.check(L.pch_first_nonfinite_row_f32(_ptr(xyz), xyz.shape[0], _ptr(out), _stream()))
+    return int(out.item())
 
 
 # ---------------------------------------------------------------------- stages B + C + D0

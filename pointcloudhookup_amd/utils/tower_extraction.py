@@ -7,17 +7,25 @@ per-cluster box fit, LAS/xlsx writing and the Python bookkeeping on the host.  L
 reference this function never raises: failures are logged and what exists is returned.
 
 Module knobs (not in the reference): ``OBB_EXTENT_ORDER`` ("unsorted" | "trimesh_sorted",
-env PCH_OBB_EXTENT_ORDER) selects the extent convention of the box fit, ``DEVICE`` the GPU.
+env PCH_OBB_EXTENT_ORDER) selects the extent convention of the box fit, ``DEVICE`` the GPU,
+``CHUNK_FAILURE`` ("reference" | "noise", env PCH_CHUNK_FAILURE) what a chunk that scikit-learn
+would reject (NaN/inf coordinates) does.  "reference" is what the reference really does, recorded
+in tests/golden/refrun_nonfinite.npz: it logs the failure of that chunk and then its own
+``finally: del chunk, clustering, chunk_labels`` (reference :120-122) raises UnboundLocalError out
+of extract_towers, because ``clustering`` was never bound.  "noise" is the behaviour its
+``except`` clause evidently intended: the chunk stays unlabelled and the run continues.
 """
 from __future__ import annotations
 
 import os
+import sys
 from pathlib import Path
 
 import numpy as np
 
 OBB_EXTENT_ORDER = os.environ.get("PCH_OBB_EXTENT_ORDER", "unsorted")
 DEVICE = os.environ.get("PCH_DEVICE", "cuda:0")
+CHUNK_FAILURE = os.environ.get("PCH_CHUNK_FAILURE", "reference")
 CHUNK_SIZE = 50000                                     # utils/tower_extraction.py:96
 
 
@@ -90,17 +98,24 @@ def extract_towers(
     log("\n=== 开始聚类处理 ===")
     progress(20)
     clusters = dict(ground=gf, nclusters=0)
+    bad_chunks = _rejected_chunks(filtered, ops) if n_f else {}
     try:
         if n_f:
             labels, _, k = ops.dbscan(filtered, eps, min_points, CHUNK_SIZE, aabb=gf["aabb"])
             perm, offsets, stats = ops.segment_by_label(labels, filtered, k)
             clusters.update(labels=labels, nclusters=k, perm=perm, offsets=offsets, stats=stats)
-        for i in range(n_chunks):
-            log(f"处理分块 {i + 1}/{n_chunks} ({min(CHUNK_SIZE, n_f - i * CHUNK_SIZE)}点)")
-            progress(20 + int(50 * (i + 1) / n_chunks))
     except Exception as e:
-        # the reference loses single chunks (:118-119); one fused pass loses them together
+        # all chunks run in one device pass, so a library error concerns all of them
         log(f"⚠️ 分块聚类失败（块0-{max(n_chunks - 1, 0)}）: {str(e)}")
+        bad_chunks = {}
+    for i in range(n_chunks):
+        log(f"处理分块 {i + 1}/{n_chunks} ({min(CHUNK_SIZE, n_f - i * CHUNK_SIZE)}点)")
+        if i in bad_chunks:                                            # reference :118-122
+            log(f"⚠️ 分块聚类失败（块{i}）: {bad_chunks[i]}")
+            if CHUNK_FAILURE == "reference":
+                raise UnboundLocalError(_UNBOUND_MSG)
+            continue
+        progress(20 + int(50 * (i + 1) / n_chunks))
 
     # ---- tower detection + de-dup (reference :125-218)
     k = int(clusters["nclusters"])
@@ -144,6 +159,32 @@ def extract_towers(
     progress(100)
     log("✅ 杆塔提取完成")
     return tower_obbs
+
+
+_UNBOUND_MSG = ("local variable 'clustering' referenced before assignment" if sys.version_info < (3, 11)
+                else "cannot access local variable 'clustering' where it is not associated with a value")
+
+
+def _rejected_chunks(filtered, ops):
+    """{chunk index: first sentence of scikit-learn's ValueError} for the chunks DBSCAN.fit's input
+    validation rejects (NaN/inf).  The library leaves such chunks unlabelled; the common case - no
+    such row anywhere - costs one small kernel."""
+    out = {}
+    n = int(filtered.shape[0])
+    row = ops.first_nonfinite_row(filtered)
+    while row >= 0:
+        c = row // CHUNK_SIZE
+        chunk = filtered[c * CHUNK_SIZE:(c + 1) * CHUNK_SIZE].cpu().numpy()
+        out[c] = ("Input X contains NaN." if np.isnan(chunk).any()
+                  else "Input X contains infinity or a value too large for dtype('float32').")
+        if CHUNK_FAILURE == "reference":
+            break                                                      # nothing after the first failure is reached
+        nxt = (c + 1) * CHUNK_SIZE
+        if nxt >= n:
+            break
+        row = ops.first_nonfinite_row(filtered[nxt:])
+        row = row + nxt if row >= 0 else -1
+    return out
 
 
 def _save_tower_las(points, colors, header_info, output_path, log_callback=None):

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Condenses rocprofv3 output directories into the small, tracked summaries in profiles/.
 
-  python profiles/summarize.py <round tag> <stats dir> <pmc_fetch dir> <pmc_write dir> <points>
+  python profiles/summarize.py <tag> <stats dir> <pmc_fetch dir> <pmc_write dir> <points> [<kind> <frame>]
 
 Writes profiles/<tag>_kernel_stats.csv (per-kernel calls / avg / total from --kernel-trace
 --stats), profiles/<tag>_pmc_traffic.csv (FETCH_SIZE / WRITE_SIZE per launch from the two
-separate --pmc passes) and profiles/traffic.json (what bench.py attaches as `traffic`).
+separate --pmc passes) and merges the per-launch byte counts into profiles/traffic.json under
+the key "<kind>/<frame>/<points>" (what bench.py attaches as `traffic` for the SAME workload).
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for
 wide coalesced streams (MI355X_MICROARCH.md, HBM section), so the read side is reported raw
 AND doubled; the doubled figure is the one compared with algorithmic bytes.
@@ -18,6 +19,8 @@ import os
 import sys
 
 tag, stats_dir, fetch_dir, write_dir, points = sys.argv[1:6]
+kind = sys.argv[6] if len(sys.argv) > 6 else "corridor"
+frame = sys.argv[7] if len(sys.argv) > 7 else "offset"
 here = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -49,9 +52,11 @@ names = {"ms_summary_k": "mean_summary", "ms_walk_k": "mean_walk", "ms_level2_k"
          "gf_compact_k<0>": "gf_compact", "gf_compact_k<1>": "gf_compact_fb", "db_chunksort_k": "db_chunksort", "sel_hist_k<0>": "sel_hist0",
          "sel_hist_k<1>": "sel_hist1", "sel_hist_k<2>": "sel_hist2", "rs_scatter_k": "radix_scatter",
          "rs_hist_k": "radix_hist", "db_gather_k": "db_gather", "db_keys_k": "db_keys",
-         "sg_stats_k": "seg_stats", "db_label_k": "db_label", "db_cellbox_k": "db_cellbox"}
-traffic = {"points": int(points), "unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, KiB->B)",
-           "kernels": {}}
+         "sg_stats_k": "seg_stats", "db_label_k": "db_label", "db_cellbox_k": "db_cellbox",
+         "db_union_face_k": "db_union0", "db_rowtab_k": "db_rowtab", "db_cellstats_k": "db_cellstats",
+         "db_cells_k": "db_cells"}
+traffic = {"points": int(points), "kind": kind, "frame": frame, "source": tag,
+           "unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, KiB->B)", "kernels": {}}
 with open(os.path.join(here, f"{tag}_pmc_traffic.csv"), "w") as f:
     f.write("kernel,launches,fetch_bytes_raw_per_launch,fetch_bytes_x2_per_launch,write_bytes_per_launch\n")
     for k in sorted(set(fetch) | set(write), key=lambda k: -sum(fetch.get(k, [0]))):
@@ -61,5 +66,13 @@ with open(os.path.join(here, f"{tag}_pmc_traffic.csv"), "w") as f:
         f.write(f"{k},{max(len(fl), len(wl))},{fb:.0f},{2 * fb:.0f},{wb:.0f}\n")
         if k in names:
             traffic["kernels"][names[k]] = int(2 * fb + wb)
-json.dump(traffic, open(os.path.join(here, "traffic.json"), "w"), indent=1)
+tpath = os.path.join(here, "traffic.json")
+try:
+    allt = json.load(open(tpath))
+    if "workloads" not in allt:
+        allt = {"workloads": {}}
+except Exception:
+    allt = {"workloads": {}}
+allt["workloads"][f"{kind}/{frame}/{int(points)}"] = traffic
+json.dump(allt, open(tpath, "w"), indent=1)
 print(open(os.path.join(here, f"{tag}_pmc_traffic.csv")).read())

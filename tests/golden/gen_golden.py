@@ -100,8 +100,10 @@ def numpy_stats():
                            centroid_bits=[int(v) for v in c.view(np.uint32)],
                            pct25_bits=int(np.float32(p).view(np.uint32)),
                            centroid=[float(v) for v in c], pct25=float(p))
-    json.dump(out, open(os.path.join(HERE, "numpy_stats.json"), "w"), indent=1)
     print("numpy_stats", {k: v["centroid"] for k, v in out.items()})
+    out["_numpy"] = {"version": np.__version__, "major": int(np.__version__.split(".")[0]),
+                     "note": "np.percentile's index arithmetic is float32 under numpy >= 2 (NEP 50); the device select mirrors that"}
+    json.dump(out, open(os.path.join(HERE, "numpy_stats.json"), "w"), indent=1)
 
 
 def kuangxuan_boxes():

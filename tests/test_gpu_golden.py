@@ -114,3 +114,40 @@ def test_dropin_empty_cloud_like_reference(cuda, tmp_path, monkeypatch):
     logs, prog = [], []
     assert te.extract_towers(path, progress_callback=prog.append, log_callback=logs.append) == []
     assert logs == [str(s) for s in g["logs"]] and prog == g["progress"].tolist()
+
+
+def test_dropin_chunk_failure_like_reference(cuda, tmp_path, monkeypatch):
+    """refrun_nonfinite: one NaN x makes the float32 centroid's x NaN, so every chunk holds NaN.
+    scikit-learn rejects the first chunk, the reference logs that - and then its own `finally: del
+    ... clustering ...` raises UnboundLocalError out of extract_towers (recorded in the fixture).
+    LAS integers cannot hold a NaN, so it is injected behind the float32 cast."""
+    from pointcloudhookup_amd.utils import tower_extraction as te
+    g, x, y, z, _, kwargs = _load("nonfinite")
+    assert str(g["raised"]).startswith("UnboundLocalError")
+    sc, of = g["scales"], g["offsets"]
+    xf = np.where(np.isnan(x), of[0], x)
+    XYZ = np.stack([np.round((c - of[a]) / sc[a]) for a, c in enumerate((xf, y, z))], axis=1).astype(np.int32)
+    path = str(tmp_path / "cloud.las")
+    las.write(path, las.LasHeader(point_format=3, version=(1, 2), scales=sc, offsets=of), XYZ)
+    bad = int(np.flatnonzero(np.isnan(x))[0])
+    real_cast = ops.cast_f32
+
+    def cast_with_nan(t):
+        out = real_cast(t)
+        out[bad, 0] = float("nan")
+        return out
+
+    monkeypatch.setattr(ops, "cast_f32", cast_with_nan)
+    monkeypatch.chdir(tmp_path)
+    ref_logs = [str(s) for s in g["logs"]]
+    for mode in ("reference", "noise"):
+        monkeypatch.setattr(te, "CHUNK_FAILURE", mode)
+        logs, prog = [], []
+        if mode == "reference":
+            with pytest.raises(UnboundLocalError):
+                te.extract_towers(path, progress_callback=prog.append, log_callback=logs.append)
+            assert logs[:-1] == ref_logs[:-1] and prog == g["progress"].tolist()
+            assert logs[-1] == ref_logs[-1].split("\n")[0]             # first sentence of sklearn's message
+        else:
+            assert te.extract_towers(path, progress_callback=prog.append, log_callback=logs.append) == []
+            assert logs[:len(ref_logs) - 1] == ref_logs[:-1] and logs[-1] == "✅ 杆塔提取完成" and prog[-1] == 100

@@ -38,6 +38,39 @@ def test_voxel_matches_oracle(cuda, n, voxel, chunk):
     np.testing.assert_array_equal(mean.cpu().numpy(), rmean)        # in-order f64 sums: bit exact
 
 
+@pytest.mark.parametrize("case", ["dense_core", "one_voxel_20000", "wide_keys_u64", "huge_keys_general",
+                                  "ragged_tiles", "tower_like", "all_equal_points"])
+def test_voxel_paths_match_oracle(cuda, case):
+    """Every path of the voxel finisher: units sorted inside LDS with 32-bit and 64-bit items, units too
+    large for LDS (LSD passes in global memory), keys too wide for an LDS item, one voxel holding more rows
+    than an LDS tile (in-order sum across tiles), ragged partition tiles."""
+    rng = np.random.default_rng(hash(case) % 2**32)
+    if case == "dense_core":              # 60 000 points inside 2 m: level-1 units far above the LDS capacity
+        pts, voxel, chunk = rng.normal(0, 0.6, (60000, 3)) + OFFSET, 0.05, 0
+    elif case == "one_voxel_20000":       # a single voxel with 20 000 rows + scattered others
+        pts = np.vstack([rng.random((20000, 3)) * 0.09 + 5.0, rng.random((3000, 3)) * 40.0]) + OFFSET
+        pts, voxel, chunk = pts[rng.permutation(len(pts))], 0.1, 0
+    elif case == "wide_keys_u64":         # 2 km x 2 km x 100 m at 1 cm: 18+18+14 = 50 key bits -> 64-bit LDS items
+        pts, voxel, chunk = rng.random((30000, 3)) * [2000.0, 2000.0, 100.0] + OFFSET, 0.01, 0
+    elif case == "huge_keys_general":     # 21+21+21 = 63 key bits: too wide for an LDS item
+        pts, voxel, chunk = rng.random((20000, 3)) * 2000.0 + OFFSET, 0.001, 6000
+    elif case == "ragged_tiles":          # chunk sizes that are no multiple of the 4096-row partition tile
+        pts, voxel, chunk = rng.random((50001, 3)) * [50.0, 20.0, 5.0] + OFFSET, 0.25, 12345
+    elif case == "tower_like":            # ground plane + a dense column, two chunks
+        g = np.column_stack([rng.uniform(0, 50, 150000), rng.uniform(0, 100, 150000), rng.normal(0, 0.05, 150000)])
+        t = rng.normal([25, 50, 22], [2.5, 2.5, 9], (150000, 3))
+        pts = np.vstack([g, t])
+        pts, voxel, chunk = pts[rng.permutation(len(pts))] + OFFSET, 0.2, 200000
+    else:                                 # all_equal_points: zero key bits
+        pts, voxel, chunk = np.tile(OFFSET + [1.0, 2.0, 3.0], (9000, 1)), 0.1, 4000
+    idx, mean, count, offs = ops.voxel_downsample(_dev(pts, cuda), voxel, chunk)
+    ridx, rmean, rcount, roffs = ovx.voxel_down_sample_chunked(pts, voxel, chunk if chunk else len(pts))
+    np.testing.assert_array_equal(offs.cpu().numpy(), roffs)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_array_equal(count.cpu().numpy(), rcount)
+    np.testing.assert_array_equal(mean.cpu().numpy(), rmean)
+
+
 def test_voxel_single_voxel_and_negative_coords(cuda):
     pts = np.array([[-1.0, -2.0, -3.0], [-1.01, -2.01, -3.01], [-0.99, -1.99, -2.99]])
     idx, mean, count, _ = ops.voxel_downsample(_dev(pts, cuda), 5.0, 0)
@@ -328,7 +361,7 @@ def test_segment_by_label(cuda, n, K):
     np.testing.assert_array_equal(perm[offs[K]:], np.flatnonzero(labels == -1))
 
 
-def test_dbscan_chunk_local_sort_equals_global_sort(cuda, monkeypatch):
+def test_dbscan_chunk_local_sort_equals_global_sort(cuda):
     """The chunk-local cell sort (one workgroup per chunk) and the general global radix sort feed
     the same clustering: labels and core masks must agree, with ragged last chunk, a NaN chunk and
     a chunk size that is not a multiple of anything."""
@@ -341,11 +374,13 @@ def test_dbscan_chunk_local_sort_equals_global_sort(cuda, monkeypatch):
     X[60001, 2] = np.nan
     dev = _dev(X, cuda)
     for chunk in (50000, 7777, 1000, 0):
-        monkeypatch.setenv("PCH_DBSCAN_SORT", "chunk")
-        la, ca, ka = ops.dbscan(dev, 8.0, 80, chunk, want_core=True)
-        monkeypatch.setenv("PCH_DBSCAN_SORT", "global")
-        lb, cb, kb = ops.dbscan(dev, 8.0, 80, chunk, want_core=True)
-        monkeypatch.delenv("PCH_DBSCAN_SORT", raising=False)       # the library's own choice (by chunk count)
+        try:
+            ops.set_dbscan_sort_mode("chunk")
+            la, ca, ka = ops.dbscan(dev, 8.0, 80, chunk, want_core=True)
+            ops.set_dbscan_sort_mode("global")
+            lb, cb, kb = ops.dbscan(dev, 8.0, 80, chunk, want_core=True)
+        finally:
+            ops.set_dbscan_sort_mode("auto")                       # the library's own choice (by chunk count)
         lc, cc, kc = ops.dbscan(dev, 8.0, 80, chunk, want_core=True)
         assert ka == kb == kc
         assert torch.equal(la, lb) and torch.equal(ca, cb) and torch.equal(la, lc) and torch.equal(ca, cc)
@@ -364,3 +399,52 @@ def test_ground_filter_sizes_around_tile_edges(cuda, n):
     assert got["used_fallback"] == ref["used_fallback"] and got["count"] == len(ref["filtered"])
     np.testing.assert_array_equal(got["points"].cpu().numpy().view(np.uint32), ref["filtered"].view(np.uint32))
     np.testing.assert_array_equal(got["index"].cpu().numpy(), np.flatnonzero(ref["keep"]))
+
+
+@pytest.mark.parametrize("mode", ["chunk", "global"])
+def test_dbscan_nan_chunks_first_last_adjacent(cuda, oracle_clib, mode):
+    """NaN/inf chunks at the front, at the end and side by side keep their own cell (never core),
+    so the chunk -> cell table stays complete under both cell sorts; the other chunks are clustered
+    as if alone and numbered like the reference (a failed chunk does not advance the counter)."""
+    rng = np.random.default_rng(5)
+    chunk, nch = 3000, 7
+    X = np.vstack([rng.normal([c * 40.0, 0, 20], [2, 2, 6], (chunk, 3)) for c in range(nch)]).astype(np.float32)
+    for c, col, val in ((0, 0, np.nan), (3, 1, np.inf), (4, 2, -np.inf), (6, 0, np.nan)):
+        X[c * chunk + int(rng.integers(0, chunk)), col] = val
+    want = odb.dbscan_chunked(X, 8.0, 80, chunk, fit="c")
+    assert (want[:chunk] == -1).all() and (want[-chunk:] == -1).all() and want.max() >= 2
+    try:
+        ops.set_dbscan_sort_mode(mode)
+        lab, core, k = ops.dbscan(_dev(X, cuda), 8.0, 80, chunk, want_core=True)
+    finally:
+        ops.set_dbscan_sort_mode("auto")
+    np.testing.assert_array_equal(lab.cpu().numpy(), want)
+    assert k == want.max() + 1
+    assert ops.first_nonfinite_row(_dev(X, cuda)) == int(np.flatnonzero(~np.isfinite(X).all(1))[0])
+    assert ops.first_nonfinite_row(_dev(X[chunk:3 * chunk], cuda)) == -1
+
+
+def test_entry_points_reject_host_pointers_and_keep_the_callers_device(cuda):
+    import ctypes as C
+    from pointcloudhookup_amd import _lib
+    L = _lib.lib()
+    host = np.zeros((16, 3), np.float32)
+    out = torch.zeros(3, dtype=torch.float32, device=cuda)
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device=cuda)
+    rc = L.pch_mean_seq_f32(host.ctypes.data_as(C.c_void_p), 16, out.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    assert rc == -1 and b"device pointer" in L.pch_last_error()
+    before = torch.cuda.current_device()
+    ops.mean_seq_f32(torch.ones((100, 3), dtype=torch.float32, device=cuda))
+    assert torch.cuda.current_device() == before
+
+
+def test_count_at_offset_is_an_integer_above_2_pow_24(cuda):
+    """The count kept at the first threshold travels as an integer (2^24 + 1 is not a float32)."""
+    n = (1 << 24) + 1 + 5000
+    raw = torch.zeros((n, 3), dtype=torch.float32, device=cuda)
+    raw[5000:, 2] = 10.0                      # percentile(25) = 10 - mean; z - mean > base + 3 never holds ...
+    raw[:5000, 2] = -100.0                    # ... so shift: 5000 low rows, the rest 110 above them
+    gf = ops.ground_filter(raw, 0.01, 3.0, 1.0, 1000, want_index=False)
+    assert gf["count"] == (1 << 24) + 1 and gf["count_at_offset"] == (1 << 24) + 1
+    g2 = ops.tower_clusters(raw, pct=0.01, segment=False)[0]
+    assert g2["count_at_offset"] == (1 << 24) + 1

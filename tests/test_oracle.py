@@ -66,7 +66,12 @@ def test_dbscan_chunk_offsets_follow_reference_rule():
 # ------------------------------------------------------------------ stage B pins
 def test_numpy_stats_golden():
     gold = json.load(open(os.path.join(GOLD, "numpy_stats.json")))
+    # the device percentile mirrors numpy >= 2 (float32 index arithmetic under NEP 50); numpy 1.x promotes
+    # (n-1)*q to float64 and can pick another order statistic above 2^24 rows - a different reference
+    assert int(np.__version__.split(".")[0]) == gold["_numpy"]["major"] == 2
     for n, g in gold.items():
+        if n.startswith("_"):
+            continue
         n = int(n)
         rng = np.random.default_rng(g["seed"])
         raw = (rng.random((n, 3)) * [1000.0, 100.0, 30.0] + [437000.0, 3139000.0, 80.0]).astype(np.float32)
