@@ -11,16 +11,28 @@ constexpr uint64_t GF_FLAG_AGG = 1ull << 62, GF_FLAG_INCL = 2ull << 62;
 // status: one zeroed 64-bit word per tile (2-bit flag + 32-bit value, one relaxed agent-scope atomic).
 // FORWARD PROGRESS: the caller waits for every tile in front of b, so b must be an order in which
 // workgroups START (a ticket drawn on arrival), never blockIdx - HIP promises no dispatch order.
-__device__ __forceinline__ uint32_t gf_lookback(uint64_t* __restrict__ status, int64_t b, uint32_t T) {
+// gf_announce (one lane) may publish the tile's count as soon as it is known - long before the tile needs its
+// own prefix - so that tiles behind it do not wait; gf_lookback(..., announced = true) then skips that store.
+__device__ __forceinline__ void gf_announce(uint64_t* __restrict__ status, int64_t b, uint32_t T) {
+    __hip_atomic_store(&status[b], (b == 0 ? GF_FLAG_INCL : GF_FLAG_AGG) | T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t gf_lookback(uint64_t* __restrict__ status, int64_t b, uint32_t T,
+                                                bool announced = false) {
     const int l = lane_id();
     if (b == 0) {
-        if (l == 0) __hip_atomic_store(&status[0], GF_FLAG_INCL | T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (l == 0 && !announced) __hip_atomic_store(&status[0], GF_FLAG_INCL | T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return 0;
     }
-    if (l == 0) __hip_atomic_store(&status[b], GF_FLAG_AGG | T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (l == 0 && !announced) __hip_atomic_store(&status[b], GF_FLAG_AGG | T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t excl = 0;
     bool done = false;
-    for (int64_t j = b - 1; !done; j -= 64 * GF_LOOK) {  // windows [j-64k-63, j-64k]: lane l looks at tile j-64k-l
+#ifdef PCH_LB_COUNT
+    extern __device__ unsigned long long g_lb_polls, g_lb_windows;
+#endif
+    for (int64_t j = b - 1; !done; j -= 64 * GF_LOOK) {
+#ifdef PCH_LB_COUNT
+        if (l == 0) atomicAdd(&g_lb_windows, 1ull);
+#endif  // windows [j-64k-63, j-64k]: lane l looks at tile j-64k-l
         uint64_t v[GF_LOOK];
         do {                                            // tiles in front drew their ticket earlier: they run and publish
             bool missing = false;
@@ -32,6 +44,9 @@ __device__ __forceinline__ uint32_t gf_lookback(uint64_t* __restrict__ status, i
                 missing |= (v[k] >> 62) == 0;
             }
             if (__ballot(missing) == 0) break;
+#ifdef PCH_LB_COUNT
+            if (l == 0) atomicAdd(&g_lb_polls, 1ull);
+#endif
             __builtin_amdgcn_s_sleep(1);
         } while (true);
 #pragma unroll

@@ -3,14 +3,20 @@
 // file order, one float64 running sum per voxel.
 // Reference call site: ui/import_PC.py:8-13 inside the chunk loop ui/import_PC.py:45-58.
 #include "pch_prims.h"
+#ifdef PCH_VX_STAMPS
+#define PCH_LB_COUNT
+namespace pch { __device__ unsigned long long g_lb_polls = 0, g_lb_windows = 0; }
+#endif
 #include "pch_lookback.h"
 
 namespace pch {
 
 constexpr int VX_THREADS = 256;
-constexpr int VX_MM_ROUNDS = 4;
+constexpr int VX_MM_ROUNDS = 8;
 
 // ---- per-chunk float64 min / max (ordered-uint64 atomics) ---------------------------
+// A thread takes two rows per round as three 16-byte loads (a chunk starts on a 16-byte boundary
+// when chunk_size is even; odd chunk sizes and the last row use the scalar path).
 __global__ __launch_bounds__(VX_THREADS) void vx_minmax_k(const double* __restrict__ xyz,
                                                           int64_t n, int64_t chunk_size,
                                                           int64_t blocks_per_chunk,
@@ -20,26 +26,50 @@ __global__ __launch_bounds__(VX_THREADS) void vx_minmax_k(const double* __restri
     const int64_t tile  = blockIdx.x % blocks_per_chunk;
     const int64_t cbeg = chunk * chunk_size;
     const int64_t cend = (cbeg + chunk_size < n) ? cbeg + chunk_size : n;
-    unsigned long long lo[3] = {~0ull, ~0ull, ~0ull}, hi[3] = {0ull, 0ull, 0ull};
-    for (int r = 0; r < 4; ++r) {
-        const int64_t i = cbeg + (tile * 4 + r) * VX_THREADS + threadIdx.x;
-        if (i < cend) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool nan = false;
+    auto take = [&](int a, double v) {
+        lo[a] = v < lo[a] ? v : lo[a];
+        hi[a] = v > hi[a] ? v : hi[a];
+        nan |= v != v;
+    };
+    const bool vec = ((cbeg & 1) == 0) && ((reinterpret_cast<uintptr_t>(xyz) & 15u) == 0);
+    const int64_t t0 = cbeg + tile * (VX_THREADS * VX_MM_ROUNDS);
+    if (vec) {
+        double2 q[VX_MM_ROUNDS / 2][3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const unsigned long long k = f64_ordered(xyz[3 * i + a]);
-                lo[a] = k < lo[a] ? k : lo[a];
-                hi[a] = k > hi[a] ? k : hi[a];
+        for (int r = 0; r < VX_MM_ROUNDS / 2; ++r) {
+            const int64_t i = t0 + 2 * (r * VX_THREADS + threadIdx.x);        // rows i, i+1
+            const bool both = i + 1 < cend;
+            const double2* p = reinterpret_cast<const double2*>(xyz + 3 * (both ? i : cbeg));
+            q[r][0] = p[0]; q[r][1] = p[1]; q[r][2] = p[2];
+        }
+#pragma unroll
+        for (int r = 0; r < VX_MM_ROUNDS / 2; ++r) {
+            const int64_t i = t0 + 2 * (r * VX_THREADS + threadIdx.x);
+            if (i + 1 < cend) {
+                take(0, q[r][0].x); take(1, q[r][0].y); take(2, q[r][1].x);
+                take(0, q[r][1].y); take(1, q[r][2].x); take(2, q[r][2].y);
+            } else if (i < cend) {
+                take(0, xyz[3 * i + 0]); take(1, xyz[3 * i + 1]); take(2, xyz[3 * i + 2]);
             }
         }
+    } else {
+        for (int r = 0; r < VX_MM_ROUNDS; ++r) {
+            const int64_t i = t0 + r * VX_THREADS + threadIdx.x;
+            if (i < cend) { take(0, xyz[3 * i + 0]); take(1, xyz[3 * i + 1]); take(2, xyz[3 * i + 2]); }
+        }
     }
+    unsigned long long klo[3], khi[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        lo[a] = wave_reduce_min(lo[a]);
-        hi[a] = wave_reduce_max(hi[a]);
+        // a NaN anywhere must reach the bounds kernel (it rejects the call): it is carried in the max slot
+        klo[a] = wave_reduce_min(f64_ordered(lo[a]));
+        khi[a] = wave_reduce_max(nan ? f64_ordered(__longlong_as_double(0x7FF8000000000000ll)) : f64_ordered(hi[a]));
     }
     if (lane_id() == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { sm[wave_id()][a] = lo[a]; sm[wave_id()][3 + a] = hi[a]; }
+        for (int a = 0; a < 3; ++a) { sm[wave_id()][a] = klo[a]; sm[wave_id()][3 + a] = khi[a]; }
     }
     __syncthreads();
     if (threadIdx.x < 6) {
@@ -73,6 +103,7 @@ __global__ void vx_bounds_k(const unsigned long long* __restrict__ mm, int64_t n
         int qi = (q >= 0.0 && q < 2147483647.0) ? (int)q : 2147483647;
         if (!(q == q)) qi = 2147483647;               // NaN coordinates
         atomicMax(&gmeta[a], qi);
+        if (!(fabs(lo) < INFINITY) || !(fabs(hi) < INFINITY)) atomicMax(&gmeta[3], 1);   // NaN / inf coordinates
     }
     if (voxel * 2147483647.0 < ext || !(ext == ext)) atomicMax(&gmeta[3], 1);
 }
@@ -101,16 +132,18 @@ constexpr int VP_ROUNDS  = 8;                        // rows per thread and tile
 constexpr int VP_TILE    = VP_THREADS * VP_ROUNDS;   // 4096 rows
 constexpr int VP_MAXBITS = 9;
 constexpr int VP_MAXBINS = 1 << VP_MAXBITS;
+constexpr int VF_THREADS = 512;                      // finisher workgroup (two per CU)
+constexpr int VF_WAVES   = VF_THREADS / 64;
+constexpr int VF_CAP     = VF_THREADS * VP_ROUNDS;   // 8192 rows: what one LDS sort takes
+constexpr int VF_DIGBITS = 8;                        // a batch spans at most 256 level-1 digits
 constexpr int VG_ROUNDS  = 4;                        // general (global-memory) path: rows per thread and tile
-constexpr int VG_TILE    = VP_THREADS * VG_ROUNDS;
-constexpr int VF_CAP     = 4096;                     // rows of a unit that is sorted inside LDS
-constexpr int VF_ROWBITS = 12;                       // log2(VF_CAP): local row field of a packed LDS item
+constexpr int VG_TILE    = VF_THREADS * VG_ROUNDS;
 
 struct Row { double x, y, z; };
 
 struct VoxelPlan {
     int64_t n, chunk_size, nchunks, tiles_per_chunk;
-    double  voxel;
+    double  voxel, rvoxel;   // voxel size and fl(1 / voxel)
     int     bx, by, bz;      // bits per axis
     int     T;               // bx + by + bz
     int     d1;              // level-1 digit bits
@@ -118,11 +151,23 @@ struct VoxelPlan {
     int     rem;             // T - d1: bits the finisher sorts on
 };
 
+// floor((p - voxel_min_bound) / voxel_size) exactly as IEEE float64 subtraction + DIVISION + floor give it
+// (Open3D: ref_coord = (p - min_bound) / voxel_size; floor), without paying for a division per coordinate:
+// q = d * fl(1/v) differs from fl(d / v) by less than q * 2^-51 (three roundings of 2^-53 each), so whenever q
+// is further than q * 2^-49 from the integers on both sides, both have the same floor; otherwise (a coordinate
+// on a voxel face to within rounding - common for quantised LAS data) the real division decides.
+__device__ __forceinline__ uint64_t vx_index(double p, double mb, double v, double rv) {
+    const double d = p - mb;                            // >= v/2: min_bound is half a voxel below the smallest point
+    const double q = d * rv;
+    const double fq = floor(q);
+    const double fr = q - fq, tol = q * 0x1p-49;
+    if (fr > tol && (1.0 - fr) > tol) return (uint64_t)(int64_t)fq;
+    return (uint64_t)(int64_t)floor(d / v);
+}
 __device__ __forceinline__ uint64_t vx_key(const VoxelPlan& g, const double* __restrict__ mb, const Row& q) {
-    // ref_coord = (p - voxel_min_bound) / voxel_size ; index = floor(ref_coord)   (float64, IEEE division)
-    const uint64_t ix = (uint64_t)(int64_t)floor((q.x - mb[0]) / g.voxel);
-    const uint64_t iy = (uint64_t)(int64_t)floor((q.y - mb[1]) / g.voxel);
-    const uint64_t iz = (uint64_t)(int64_t)floor((q.z - mb[2]) / g.voxel);
+    const uint64_t ix = vx_index(q.x, mb[0], g.voxel, g.rvoxel);
+    const uint64_t iy = vx_index(q.y, mb[1], g.voxel, g.rvoxel);
+    const uint64_t iz = vx_index(q.z, mb[2], g.voxel, g.rvoxel);
     return (((ix << g.by) | iy) << g.bz) | iz;
 }
 
@@ -168,20 +213,43 @@ __global__ __launch_bounds__(VP_THREADS) void vx_tilehist_k(const double* __rest
     for (int j = threadIdx.x; j < g.nb; j += VP_THREADS) tile_hist[(int64_t)blockIdx.x * g.nb + j] = hist[j];
 }
 
-// ---- level 1b: one workgroup per chunk: tile_hist -> exclusive offsets inside every bin, bin starts ----
+// ---- level 1b: one workgroup per chunk: tile_hist -> exclusive offsets inside every bin, bin starts;
+// consecutive units are then grouped into BATCHES of at most VF_CAP rows (one LDS sort each); a unit
+// that is larger on its own is a batch of one (sorted in global memory by its workgroup)
+struct VoxelBatch {
+    uint32_t row0;        // first row (absolute, in the partitioned buffer) of the units this batch reads
+    uint32_t rows;        // rows this batch sorts (0: nothing to do)
+    uint32_t span;        // rows to sweep: == rows, or the whole unit when the batch selects a part of it
+    uint16_t digit0;      // first level-1 digit of the batch
+    uint16_t ndigits;     // level-1 digits covered (>= 1)
+    uint16_t sel_lo, sel_hi;   // sel_hi > sel_lo: only rows whose NEXT 8-bit digit lies in [sel_lo, sel_hi)
+    uint32_t pad;
+};
+struct VoxelOversize { uint32_t slot, nsub; };             // a unit above VF_CAP rows and its reserved batch slots
+
 __global__ __launch_bounds__(VP_MAXBINS) void vx_binscan_k(VoxelPlan g, uint32_t* __restrict__ tile_hist,
                                                            uint32_t* __restrict__ unit_start,
-                                                           uint32_t* __restrict__ unit_count) {
+                                                           VoxelBatch* __restrict__ batches,
+                                                           uint32_t* __restrict__ nbatch,
+                                                           VoxelOversize* __restrict__ over,
+                                                           uint32_t* __restrict__ nover) {
     __shared__ uint32_t wsum[VP_MAXBINS / 64];
+    __shared__ uint32_t ucount[VP_MAXBINS], ustart[VP_MAXBINS];
     const int64_t c = blockIdx.x;
     const int b = threadIdx.x;
     uint32_t run = 0;
     if (b < g.nb) {
-        for (int64_t t = 0; t < g.tiles_per_chunk; ++t) {
-            const int64_t at = (c * g.tiles_per_chunk + t) * g.nb + b;
-            const uint32_t h = tile_hist[at];
-            tile_hist[at] = run;
-            run += h;
+        constexpr int U = 8;                               // loads of eight tiles in flight
+        for (int64_t t0 = 0; t0 < g.tiles_per_chunk; t0 += U) {
+            uint32_t h[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+                h[k] = t0 + k < g.tiles_per_chunk ? tile_hist[(c * g.tiles_per_chunk + t0 + k) * g.nb + b] : 0u;
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (t0 + k < g.tiles_per_chunk) tile_hist[(c * g.tiles_per_chunk + t0 + k) * g.nb + b] = run;
+                run += h[k];
+            }
         }
     }
     const uint32_t incl = wave_scan_incl(run);
@@ -190,9 +258,135 @@ __global__ __launch_bounds__(VP_MAXBINS) void vx_binscan_k(VoxelPlan g, uint32_t
     uint32_t base = incl - run;
     for (int w = 0; w < wave_id(); ++w) base += wsum[w];
     if (b < g.nb) {
-        unit_start[c * g.nb + b] = (uint32_t)(c * g.chunk_size) + base;
-        unit_count[c * g.nb + b] = run;
+        const uint32_t st = (uint32_t)(c * g.chunk_size) + base;
+        unit_start[c * g.nb + b] = st;
+        ucount[b] = run;
+        ustart[b] = st;
     }
+    const uint32_t nonempty = (uint32_t)__syncthreads_count(b < g.nb && run != 0);
+    if (b == 0) {                                          // greedy grouping, in digit order
+        VoxelBatch* out = batches + c * VP_MAXBINS;
+        uint32_t nbt = 0, rows = 0, first = 0;
+        const uint32_t maxdig = (g.rem >= 32) ? 1u : (g.rem + VF_DIGBITS > 32 ? (1u << (32 - g.rem)) : (1u << VF_DIGBITS));
+        auto emit = [&](uint32_t r0, uint32_t nrows, uint32_t d0, uint32_t nd) {
+            VoxelBatch v;
+            v.row0 = r0; v.rows = nrows; v.span = nrows; v.digit0 = (uint16_t)d0; v.ndigits = (uint16_t)nd;
+            v.sel_lo = 0; v.sel_hi = 0; v.pad = 0;
+            out[nbt++] = v;
+        };
+        // a batch covers the digits [first, last] of its first and last NON-EMPTY unit (empty units in between
+        // cost nothing but would widen the sort key)
+        uint32_t last = 0, seen = 0;
+        for (uint32_t d = 0; d < (uint32_t)g.nb; ++d) {
+            const uint32_t cnt = ucount[d];
+            if (cnt == 0) continue;
+            ++seen;
+            if (rows && (rows + cnt > (uint32_t)VF_CAP || d - first >= maxdig)) {   // close the open batch
+                emit(ustart[first], rows, first, last - first + 1);
+                rows = 0;
+            }
+            if (rows == 0) first = d;
+            rows += cnt;
+            last = d;
+            if (rows > (uint32_t)VF_CAP) {                 // a single unit above VF_CAP (rows == cnt here)
+                // split by its next digit into <= 2*ceil(rows/CAP)+1 parts (filled in by vx_split_k), unless
+                // batch slots or the 16-bit position field run out: then one batch, sorted in global memory
+                const uint32_t nsub = 2 * ((rows + VF_CAP - 1) / VF_CAP) + 1;
+                const uint32_t left = nonempty - seen;                    // units still to come need <= 1 slot each
+                if (rows <= 65535u && g.rem > 0 && g.rem <= 32 && nbt + nsub + left <= (uint32_t)VP_MAXBINS) {
+                    const uint32_t o = atomicAdd(nover, 1u);
+                    over[o].slot = (uint32_t)(c * VP_MAXBINS) + nbt;
+                    over[o].nsub = nsub;
+                    for (uint32_t k = 0; k < nsub; ++k) {
+                        emit(ustart[d], 0, d, 1);
+                        out[nbt - 1].span = rows;
+                    }
+                } else {
+                    emit(ustart[d], rows, d, 1);
+                }
+                rows = 0;
+            }
+        }
+        if (rows) emit(ustart[first], rows, first, last - first + 1);
+        nbatch[c] = nbt;
+    }
+}
+
+// one workgroup per oversize unit: histogram of its next 8-bit digit, then parts of <= VF_CAP rows
+__global__ __launch_bounds__(1024) void vx_split_k(VoxelPlan g, const double* __restrict__ minb,
+                                                  const Row* __restrict__ rows, VoxelBatch* __restrict__ batches,
+                                                  const VoxelOversize* __restrict__ over,
+                                                  const uint32_t* __restrict__ nover) {
+    __shared__ uint32_t hist[256];
+    const uint32_t total = *nover;
+    for (uint32_t o = blockIdx.x; o < total; o += gridDim.x) {
+        const VoxelOversize ov = over[o];
+        VoxelBatch* bt = batches + ov.slot;
+        const uint32_t s = bt[0].row0, R = bt[0].span;
+        const int64_t c = ov.slot / VP_MAXBINS;
+        const double mb[3] = {minb[3 * c + 0], minb[3 * c + 1], minb[3 * c + 2]};
+        const int sh2 = g.rem > 8 ? g.rem - 8 : 0;
+        const uint64_t remmask = (1ull << g.rem) - 1;
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < R; i0 += 4 * 1024) {
+            Row q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t i = i0 + k * 1024 + threadIdx.x;
+                q[k] = rows[s + (i < R ? i : 0)];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i0 + k * 1024 + threadIdx.x < R)
+                    atomicAdd(&hist[(uint32_t)((vx_key(g, mb, q[k]) & remmask) >> sh2) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t k = 0, acc = 0, lo = 0;
+            bool ok = true;
+            for (uint32_t d = 0; d < 256 && ok; ++d) {
+                const uint32_t h = hist[d];
+                if (h > (uint32_t)VF_CAP) { ok = false; break; }
+                if (acc + h > (uint32_t)VF_CAP) {
+                    bt[k].rows = acc; bt[k].sel_lo = (uint16_t)lo; bt[k].sel_hi = (uint16_t)d; ++k;
+                    lo = d;
+                    acc = 0;
+                }
+                acc += h;
+            }
+            if (ok) {
+                if (acc) { bt[k].rows = acc; bt[k].sel_lo = (uint16_t)lo; bt[k].sel_hi = 256; ++k; }
+            } else {                                       // one voxel column alone exceeds the LDS capacity:
+                for (uint32_t j = 0; j < ov.nsub; ++j) { bt[j].rows = 0; bt[j].sel_lo = bt[j].sel_hi = 0; }
+                bt[0].rows = R;                            // the whole unit as one batch, sorted in global memory
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// exclusive scan of the per-chunk batch counts (one workgroup); prefix[nchunks] = total
+__global__ __launch_bounds__(1024) void vx_batchscan_k(const uint32_t* __restrict__ nbatch, int64_t nchunks,
+                                                       uint32_t* __restrict__ prefix) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nchunks; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const uint32_t v = i < nchunks ? nbatch[i] : 0u;
+        const uint32_t incl = wave_scan_incl(v);
+        if (lane_id() == 63) wsum[wave_id()] = incl;
+        __syncthreads();
+        uint32_t before = carry_s, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave_id()) before += wsum[w]; tot += wsum[w]; }
+        if (i < nchunks) prefix[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) prefix[nchunks] = carry_s;
 }
 
 // ---- level 1c: stable scatter of the rows into their (chunk, digit) units -----------------------
@@ -252,19 +446,24 @@ __global__ __launch_bounds__(VP_THREADS) void vx_scatter_k(const double* __restr
 }
 
 // ---- finish ------------------------------------------------------------------------------------
+// One batch per workgroup iteration.  LDS sort: what is sorted is a 32-bit key
+//   ((level-1 digit - first digit of the batch) << rem) | (low `rem` bits of the voxel key)
+// together with the row's position in the batch (uint16); the rows themselves stay in L2.
 struct VfShared {
     union {
-        // LDS sort of one unit: packed (key << VF_ROWBITS | local row) items, two buffers
-        unsigned long long item[2][VF_CAP];      // 64 KB (the 32-bit variant uses the first half of each)
+        struct {
+            uint32_t key[2][VF_CAP];             // 64 KB
+            uint16_t perm[2][VF_CAP];            // 32 KB
+        };
         uint32_t hist[8][256];                   // general path: digit histograms of every LSD pass
     };
-    uint32_t cnt[VP_WAVES][256];                 // per-wave digit counters / offsets
+    uint32_t cnt[VF_WAVES][256];                 // per-wave digit counters / offsets (16 KB)
     uint32_t base[256];
-    uint32_t wsum[VP_WAVES];
-    uint32_t unit, nvox, vbase;
+    uint32_t wsum[VF_WAVES];
+    uint32_t ticket, vbase;
 };
 
-// block-wide exclusive scan of one value per thread (VP_THREADS threads); total returned to all
+// block-wide exclusive scan of one value per thread (VF_THREADS threads); total returned to all
 __device__ __forceinline__ uint32_t vf_block_scan(uint32_t v, uint32_t* wsum, uint32_t& total) {
     const uint32_t incl = wave_scan_incl(v);
     __syncthreads();
@@ -272,7 +471,7 @@ __device__ __forceinline__ uint32_t vf_block_scan(uint32_t v, uint32_t* wsum, ui
     __syncthreads();
     uint32_t before = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < VP_WAVES; ++w) {
+    for (int w = 0; w < VF_WAVES; ++w) {
         const uint32_t s = wsum[w];
         if (w < wave_id()) before += s;
         tot += s;
@@ -294,63 +493,183 @@ __device__ __forceinline__ void vf_emit(const VoxelPlan& g, uint64_t key, double
     out_idx[3 * slot + 0] = (int32_t)((key >> (g.bz + g.by)) & ((1ull << g.bx) - 1));
 }
 
-// P = uint32_t when rem + VF_ROWBITS <= 32, else unsigned long long
-template <typename P>
-__global__ __launch_bounds__(VP_THREADS, 4) void vx_finish_k(
-    VoxelPlan g, const double* __restrict__ minb, const uint32_t* __restrict__ unit_start,
-    const uint32_t* __restrict__ unit_count, Row* __restrict__ bufA, Row* __restrict__ bufB,
+#ifdef PCH_VX_STAMPS        // tuning builds only: where one workgroup's time goes, phase by phase
+#define VX_STAMP(k) do { __syncthreads(); if (tid == 0) { const unsigned long long _t = wall_clock64(); acc[k] += _t - t_last; t_last = _t; } } while (0)
+#else
+#define VX_STAMP(k)
+#endif
+
+__global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_k(
+    VoxelPlan g, const double* __restrict__ minb, const VoxelBatch* __restrict__ batches,
+    const uint32_t* __restrict__ batch_prefix, Row* __restrict__ bufA, Row* __restrict__ bufB,
     uint32_t* __restrict__ vstart_g, uint64_t* __restrict__ status, uint32_t* __restrict__ ticket,
     int32_t* __restrict__ out_idx, double* __restrict__ out_mean, int32_t* __restrict__ out_count,
-    int64_t* __restrict__ out_chunk_offsets, int64_t* __restrict__ out_m) {
+    int64_t* __restrict__ out_chunk_offsets, int64_t* __restrict__ out_m, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vf_raw[];
     VfShared& sh = *reinterpret_cast<VfShared*>(vf_raw);
     const int tid = threadIdx.x, w = wave_id(), l = lane_id();
-    const int64_t nunits = g.nchunks * g.nb;
-    const uint64_t remmask = g.rem >= 64 ? ~0ull : ((1ull << g.rem) - 1);
-    P* it0 = reinterpret_cast<P*>(sh.item[0]);
-    P* it1 = reinterpret_cast<P*>(sh.item[1]);
+    const uint32_t nbatches = batch_prefix[g.nchunks];
+#ifdef PCH_VX_STAMPS
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = wall_clock64();
+#endif
+    const uint64_t remmask = (1ull << g.rem) - 1;           // rem <= 54
     for (;;) {
-        __syncthreads();                                   // previous unit's LDS reads are done
-        if (tid == 0) sh.unit = atomicAdd(ticket, 1u);     // units are taken in order of arrival (look-back below)
+        __syncthreads();                                   // previous batch's LDS reads are done
+        if (tid == 0) sh.ticket = atomicAdd(ticket, 1u);   // batches are taken in order of arrival (look-back below)
         __syncthreads();
-        const int64_t u = sh.unit;
-        if (u >= nunits) return;
-        const int64_t c = u / g.nb;
-        const uint64_t dtop = (uint64_t)(u % g.nb);
-        const uint32_t s = unit_start[u], R = unit_count[u];
+        const uint32_t t = sh.ticket;
+        if (t >= nbatches) {
+#ifdef PCH_VX_STAMPS
+            if (tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&stamps[k], acc[k]);
+#endif
+            return;
+        }
+        VX_STAMP(0);
+        // chunk of batch t: last c with batch_prefix[c] <= t
+        int64_t lo = 0, hi = g.nchunks - 1;
+        while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if (batch_prefix[mid] <= t) lo = mid; else hi = mid - 1; }
+        const int64_t c = lo;
+        const VoxelBatch bt = batches[c * VP_MAXBINS + (t - batch_prefix[c])];
+        const bool first_of_chunk = t == batch_prefix[c];
+        const uint32_t s = bt.row0, R = bt.rows;
+        const bool selecting = bt.sel_hi > bt.sel_lo;
+        const uint64_t d0 = bt.digit0;
         const double mb[3] = {minb[3 * c + 0], minb[3 * c + 1], minb[3 * c + 2]};
-        const int passes = (g.rem + 7) / 8;
+        int dbits = 0;
+        while ((1u << dbits) < (uint32_t)bt.ndigits) ++dbits;
+        const int sortbits = g.rem + dbits;
         uint32_t nvox = 0;
-        const Row* fin = bufA + s;                         // where the unit's rows are when they are reduced
-        bool in_lds = false;
+        const Row* fin = bufA + s;                         // where the batch's rows are when they are reduced
+        bool in_lds = false, announced = false;
+        const uint32_t* srt = nullptr;                     // LDS path: sorted keys / their rows / voxel starts
+        const uint16_t* sperm = nullptr;
+        const uint32_t* vst = nullptr;
         if (R == 0) {
-            // empty unit: publishes zero voxels below
-        } else if (R <= (uint32_t)VF_CAP && g.rem + VF_ROWBITS <= (int)(8 * sizeof(P))) {
-            // ---------------- LDS path: load keys, stable LSD passes over packed items ----------------
+            // a reserved slot that was not needed: publishes zero voxels below
+        } else if (R <= (uint32_t)VF_CAP && sortbits <= 32) {
+            // ---------------- LDS path: keys once, stable LSD passes over (key, position) ----------------
             in_lds = true;
-            // item index of (wave, round, lane): wave w owns a block of `per` consecutive items
-            const uint32_t per = ((R + VP_WAVES * 64 - 1) / (VP_WAVES * 64)) * 64;   // multiple of 64, <= 512
+            const int passes = (sortbits + 7) / 8;
+            const uint32_t per = ((R + VF_WAVES * 64 - 1) / (VF_WAVES * 64)) * 64;   // items per wave: multiple of 64, <= 512
             const int rounds = (int)(per / 64);
-            for (uint32_t i = tid; i < R; i += VP_THREADS) {
-                const uint64_t k = vx_key(g, mb, bufA[s + i]) & remmask;
-                it0[i] = (P)((k << VF_ROWBITS) | i);
+            // The number of distinct keys (= voxels) is announced to the batches behind BEFORE the sort: the keys
+            // are inserted into an exact hash set (open addressing, 2 * VF_CAP slots in the still unused key
+            // buffers) while they are computed, so nobody waits for this batch's sort (the batch's own prefix is
+            // only fetched at the end).
+            const bool early = sortbits <= 31;             // 0xFFFFFFFF marks an empty slot
+            uint32_t* hset = &sh.key[0][0];
+            constexpr uint32_t HSLOTS = 2 * VF_CAP;
+            uint32_t fresh = 0;                            // keys this thread was the first to insert
+            auto insert = [&](uint32_t k) {
+                static_assert((HSLOTS & (HSLOTS - 1)) == 0, "power of two");
+                uint32_t h = ((k * 2654435761u) >> 8) & (HSLOTS - 1);
+                for (;;) {
+                    const uint32_t old = atomicCAS(&hset[h], 0xFFFFFFFFu, k);
+                    if (old == 0xFFFFFFFFu) { ++fresh; break; }
+                    if (old == k) break;
+                    h = (h + 1) & (HSLOTS - 1);
+                }
+            };
+            auto count_and_announce = [&]() {
+                uint32_t tot;
+                vf_block_scan(fresh, sh.wsum, tot);
+                if (tid == 0) gf_announce(status, (int64_t)t, tot);
+                __syncthreads();
+            };
+            if (early) {
+                for (uint32_t j = tid; j < HSLOTS; j += VF_THREADS) hset[j] = 0xFFFFFFFFu;
+                __syncthreads();
+            }
+            announced = early;
+            if (!selecting) {
+                uint32_t kreg[VP_ROUNDS];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {               // four rows per thread in flight
+                    Row q[VP_ROUNDS / 2];
+#pragma unroll
+                    for (int r = 0; r < VP_ROUNDS / 2; ++r) {
+                        const uint32_t i = (h * (VP_ROUNDS / 2) + r) * VF_THREADS + tid;
+                        q[r] = bufA[s + (i < R ? i : 0)];
+                    }
+#pragma unroll
+                    for (int r = 0; r < VP_ROUNDS / 2; ++r) {
+                        const int rr = h * (VP_ROUNDS / 2) + r;
+                        const uint32_t i = rr * VF_THREADS + tid;
+                        const uint64_t k = vx_key(g, mb, q[r]);
+                        kreg[rr] = (uint32_t)((((k >> g.rem) - d0) << g.rem) | (k & remmask));
+                        if (early && i < R) insert(kreg[rr]);
+                    }
+                }
+                if (early) count_and_announce();
+#pragma unroll
+                for (int r = 0; r < VP_ROUNDS; ++r) {
+                    const uint32_t i = r * VF_THREADS + tid;
+                    if (i < R) { sh.key[0][i] = kreg[r]; sh.perm[0][i] = (uint16_t)i; }
+                }
+            } else {
+                // part of an oversize unit: sweep the whole unit (it sits in L2) and keep, in file order, the rows
+                // whose next digit lies in [sel_lo, sel_hi)
+                const int sh2 = g.rem > 8 ? g.rem - 8 : 0;
+                uint32_t filled = 0;
+                constexpr int SW = 4;                      // rows per thread in flight
+                if (early) {                               // first sweep: distinct keys only
+                    for (uint32_t t0 = 0; t0 < bt.span; t0 += SW * VF_THREADS) {
+                        Row q[SW];
+#pragma unroll
+                        for (int k = 0; k < SW; ++k) {
+                            const uint32_t i = t0 + k * VF_THREADS + tid;
+                            q[k] = bufA[s + (i < bt.span ? i : 0)];
+                        }
+#pragma unroll
+                        for (int k = 0; k < SW; ++k) {
+                            const uint32_t i = t0 + k * VF_THREADS + tid;
+                            const uint32_t kr = (uint32_t)(vx_key(g, mb, q[k]) & remmask);
+                            const uint32_t d2 = (kr >> sh2) & 255u;
+                            if (i < bt.span && d2 >= bt.sel_lo && d2 < bt.sel_hi) insert(kr);
+                        }
+                    }
+                    count_and_announce();
+                }
+                for (uint32_t t0 = 0; t0 < bt.span; t0 += SW * VF_THREADS) {
+                    Row q[SW];
+#pragma unroll
+                    for (int k = 0; k < SW; ++k) {
+                        const uint32_t i = t0 + k * VF_THREADS + tid;
+                        q[k] = bufA[s + (i < bt.span ? i : 0)];
+                    }
+#pragma unroll
+                    for (int k = 0; k < SW; ++k) {
+                        const uint32_t i = t0 + k * VF_THREADS + tid;
+                        if (t0 + k * VF_THREADS >= bt.span) break;                  // workgroup-uniform
+                        const uint32_t kr = (uint32_t)(vx_key(g, mb, q[k]) & remmask);
+                        const uint32_t d2 = (kr >> sh2) & 255u;
+                        const bool sel = i < bt.span && d2 >= bt.sel_lo && d2 < bt.sel_hi;
+                        const uint64_t m = __ballot(sel);
+                        uint32_t tot;
+                        const uint32_t wbase = vf_block_scan(l == 0 ? (uint32_t)__popcll(m) : 0u, sh.wsum, tot);
+                        const uint32_t at = filled + __shfl(wbase, 0, 64) + (uint32_t)__popcll(m & lanemask_lt());
+                        if (sel) { sh.key[0][at] = kr; sh.perm[0][at] = (uint16_t)i; }
+                        filled += tot;
+                    }
+                }
             }
             __syncthreads();
-            P* src = it0;
-            P* dst = it1;
+            VX_STAMP(1);
+            int cur = 0;
             for (int p = 0; p < passes; ++p) {
-                const int shift = VF_ROWBITS + 8 * p;
-                for (int j = tid; j < VP_WAVES * 256; j += VP_THREADS) (&sh.cnt[0][0])[j] = 0;
+                const int shift = 8 * p;
+                for (int j = tid; j < VF_WAVES * 256; j += VF_THREADS) (&sh.cnt[0][0])[j] = 0;
                 __syncthreads();
-                P item[VP_ROUNDS];
-                uint32_t rank[VP_ROUNDS];
+                uint32_t kk[VP_ROUNDS], rank[VP_ROUNDS];
+                uint16_t pp[VP_ROUNDS];
 #pragma unroll
                 for (int r = 0; r < VP_ROUNDS; ++r) {
                     if (r < rounds) {                      // wave-uniform
                         const uint32_t i = w * per + r * 64 + l;
                         const bool valid = i < R;
-                        item[r] = valid ? src[i] : (P)0;
-                        const uint32_t d = (uint32_t)(item[r] >> shift) & 255u;
+                        kk[r] = valid ? sh.key[cur][i] : 0u;
+                        pp[r] = valid ? sh.perm[cur][i] : (uint16_t)0;
+                        const uint32_t d = (kk[r] >> shift) & 255u;
                         uint32_t np;
                         const uint32_t rk = vx_match<8>(d, valid, np);
                         const uint32_t prior = sh.cnt[w][d];
@@ -364,14 +683,14 @@ __global__ __launch_bounds__(VP_THREADS, 4) void vx_finish_k(
                 uint32_t tot = 0;
                 if (tid < 256) {
 #pragma unroll
-                    for (int w2 = 0; w2 < VP_WAVES; ++w2) tot += sh.cnt[w2][tid];
+                    for (int w2 = 0; w2 < VF_WAVES; ++w2) tot += sh.cnt[w2][tid];
                 }
                 uint32_t all;
                 const uint32_t ex = vf_block_scan(tid < 256 ? tot : 0u, sh.wsum, all);
                 if (tid < 256) {
                     uint32_t run = ex;
 #pragma unroll
-                    for (int w2 = 0; w2 < VP_WAVES; ++w2) {
+                    for (int w2 = 0; w2 < VF_WAVES; ++w2) {
                         const uint32_t cc = sh.cnt[w2][tid];
                         sh.cnt[w2][tid] = run;
                         run += cc;
@@ -383,41 +702,41 @@ __global__ __launch_bounds__(VP_THREADS, 4) void vx_finish_k(
                     if (r < rounds) {
                         const uint32_t i = w * per + r * 64 + l;
                         if (i < R) {
-                            const uint32_t d = (uint32_t)(item[r] >> shift) & 255u;
-                            dst[sh.cnt[w][d] + rank[r]] = item[r];
+                            const uint32_t at = sh.cnt[w][(kk[r] >> shift) & 255u] + rank[r];
+                            sh.key[cur ^ 1][at] = kk[r];
+                            sh.perm[cur ^ 1][at] = pp[r];
                         }
                     }
                 }
                 __syncthreads();
-                P* tswap = src; src = dst; dst = tswap;
+                cur ^= 1;
             }
-            // ---- voxel heads of the sorted items; voxel v starts at item vstart[v] (kept in `dst`, as P)
+            VX_STAMP(2);
+            // ---- voxel heads of the sorted keys; voxel v starts at item key[cur^1][v]
             uint32_t heads = 0;
             const uint32_t i0 = tid * VP_ROUNDS;            // 8 consecutive items per thread
-            P mine[VP_ROUNDS];
             bool hd[VP_ROUNDS];
 #pragma unroll
             for (int j = 0; j < VP_ROUNDS; ++j) {
                 const uint32_t i = i0 + j;
-                mine[j] = i < R ? src[i] : (P)0;
-                const P prev = (i > 0 && i < R) ? src[i - 1] : (P)0;
-                hd[j] = i < R && (i == 0 || (mine[j] >> VF_ROWBITS) != (prev >> VF_ROWBITS));
+                hd[j] = i < R && (i == 0 || sh.key[cur][i] != sh.key[cur][i - 1]);
                 heads += hd[j];
             }
             uint32_t vi = vf_block_scan(heads, sh.wsum, nvox);
 #pragma unroll
             for (int j = 0; j < VP_ROUNDS; ++j)
-                if (hd[j]) dst[vi++] = (P)(i0 + j);
+                if (hd[j]) sh.key[cur ^ 1][vi++] = i0 + j;
             __syncthreads();
-            if (tid == 0) sh.nvox = nvox;
-            // (src = sorted items, dst = voxel starts) are read below
-            it0 = src; it1 = dst;                            // remembered for the reduce; restored per unit below
+            srt = sh.key[cur];
+            sperm = sh.perm[cur];
+            vst = sh.key[cur ^ 1];
         } else {
-            // ---------------- general path: LSD passes over the rows in global memory ----------------
-            for (int j = tid; j < 8 * 256; j += VP_THREADS) (&sh.hist[0][0])[j] = 0;
+            // ---------------- general path (one oversize unit): LSD passes over the rows in global memory ----------------
+            const int passes = (g.rem + 7) / 8;
+            for (int j = tid; j < 8 * 256; j += VF_THREADS) (&sh.hist[0][0])[j] = 0;
             __syncthreads();
-            const int np = passes > 8 ? 8 : passes;          // rem <= 63
-            for (uint32_t i = tid; i < R; i += VP_THREADS) {
+            const int np = passes > 8 ? 8 : passes;
+            for (uint32_t i = tid; i < R; i += VF_THREADS) {
                 const uint64_t k = vx_key(g, mb, bufA[s + i]) & remmask;
                 for (int p = 0; p < np; ++p) atomicAdd(&sh.hist[p][(k >> (8 * p)) & 255u], 1u);
             }
@@ -430,7 +749,7 @@ __global__ __launch_bounds__(VP_THREADS, 4) void vx_finish_k(
                 if (tid < 256) sh.base[tid] = ex;
                 __syncthreads();
                 for (uint32_t t0 = 0; t0 < R; t0 += VG_TILE) {
-                    for (int j = tid; j < VP_WAVES * 256; j += VP_THREADS) (&sh.cnt[0][0])[j] = 0;
+                    for (int j = tid; j < VF_WAVES * 256; j += VF_THREADS) (&sh.cnt[0][0])[j] = 0;
                     __syncthreads();
                     const uint32_t segb = t0 + w * (64 * VG_ROUNDS);
                     Row q[VG_ROUNDS];
@@ -456,7 +775,7 @@ __global__ __launch_bounds__(VP_THREADS, 4) void vx_finish_k(
                     if (tid < 256) {
                         uint32_t run = sh.base[tid];
 #pragma unroll
-                        for (int w2 = 0; w2 < VP_WAVES; ++w2) {
+                        for (int w2 = 0; w2 < VF_WAVES; ++w2) {
                             const uint32_t cc = sh.cnt[w2][tid];
                             sh.cnt[w2][tid] = run;
                             run += cc;
@@ -476,7 +795,7 @@ __global__ __launch_bounds__(VP_THREADS, 4) void vx_finish_k(
             fin = a;
             // ---- voxel heads: vstart_g[s + v] = first row of voxel v (rows are physically sorted now)
             uint32_t carry = 0;
-            for (uint32_t t0 = 0; t0 < R; t0 += VP_TILE) {
+            for (uint32_t t0 = 0; t0 < R; t0 += VF_THREADS * VP_ROUNDS) {
                 const uint32_t i0 = t0 + tid * VP_ROUNDS;
                 uint64_t prevk = 0;
                 if (i0 > 0 && i0 < R) prevk = vx_key(g, mb, fin[i0 - 1]);
@@ -502,38 +821,40 @@ __global__ __launch_bounds__(VP_THREADS, 4) void vx_finish_k(
             __threadfence_block();
             __syncthreads();
         }
-        // ---- first output slot of this unit: look-back over the units in front (ticket order)
+#ifdef PCH_VX_STAMPS
+        if (tid == 0) { acc[6] += (R != 0 && !in_lds) ? 1 : 0; acc[7] += (R == 0) ? 1 : 0; }
+#endif
+        VX_STAMP(3);
+        // ---- first output slot of this batch: look-back over the batches in front (ticket order)
         if (w == 0) {
-            const uint32_t e = gf_lookback(status, u, nvox);
+            const uint32_t e = gf_lookback(status, (int64_t)t, nvox, announced);
             if (l == 0) sh.vbase = e;
         }
         __syncthreads();
         const int64_t vbase = sh.vbase;
+        VX_STAMP(4);
         if (tid == 0) {
-            if (dtop == 0 && out_chunk_offsets) out_chunk_offsets[c] = vbase;
-            if (u == nunits - 1) {
+            if (first_of_chunk && out_chunk_offsets) out_chunk_offsets[c] = vbase;
+            if (t == nbatches - 1) {
                 *out_m = vbase + nvox;
                 if (out_chunk_offsets) out_chunk_offsets[g.nchunks] = vbase + nvox;
             }
         }
         // ---- reduce: one thread per voxel, rows added in file order (AccumulatedPoint::AddPoint)
         if (in_lds) {
-            const P* srt = it0;
-            const P* vst = it1;
-            for (uint32_t v = tid; v < nvox; v += VP_THREADS) {
-                const uint32_t a0 = (uint32_t)vst[v], a1 = v + 1 < nvox ? (uint32_t)vst[v + 1] : R;
+            for (uint32_t v = tid; v < nvox; v += VF_THREADS) {
+                const uint32_t a0 = vst[v], a1 = v + 1 < nvox ? vst[v + 1] : R;
                 double ax = 0.0, ay = 0.0, az = 0.0;
                 for (uint32_t i = a0; i < a1; ++i) {
-                    const Row q = bufA[s + ((uint32_t)srt[i] & (uint32_t)(VF_CAP - 1))];
+                    const Row q = bufA[s + sperm[i]];
                     ax += q.x; ay += q.y; az += q.z;
                 }
-                const uint64_t key = (dtop << g.rem) | ((uint64_t)(srt[a0] >> VF_ROWBITS));
+                const uint64_t sk = srt[a0];
+                const uint64_t key = ((d0 + (sk >> g.rem)) << g.rem) | (sk & remmask);
                 vf_emit(g, key, ax, ay, az, a1 - a0, vbase + v, out_idx, out_mean, out_count);
             }
-            it0 = reinterpret_cast<P*>(sh.item[0]);
-            it1 = reinterpret_cast<P*>(sh.item[1]);
         } else {
-            for (uint32_t v = tid; v < nvox; v += VP_THREADS) {
+            for (uint32_t v = tid; v < nvox; v += VF_THREADS) {
                 const uint32_t a0 = vstart_g[s + v], a1 = v + 1 < nvox ? vstart_g[s + v + 1] : R;
                 double ax = 0.0, ay = 0.0, az = 0.0;
                 for (uint32_t i = a0; i < a1; ++i) {
@@ -544,6 +865,7 @@ __global__ __launch_bounds__(VP_THREADS, 4) void vx_finish_k(
                 vf_emit(g, key, ax, ay, az, a1 - a0, vbase + v, out_idx, out_mean, out_count);
             }
         }
+        VX_STAMP(5);
     }
 }
 
@@ -552,7 +874,10 @@ struct VoxelWs {
     double*   minb;
     int*      gmeta;
     Row      *bufA, *bufB;
-    uint32_t *tile_hist, *unit_start, *unit_count, *vstart, *ticket;
+    uint32_t *tile_hist, *unit_start, *nbatch, *batch_prefix, *vstart, *ticket;
+    VoxelBatch* batches;
+    VoxelOversize* over;
+    uint32_t* nover;
     uint64_t* status;
     size_t    clear_bytes;       // ticket .. end of status: zeroed before the finisher
 };
@@ -573,9 +898,13 @@ static void voxel_plan(Arena& a, int64_t n, int64_t nchunks, int64_t chunk_size,
     w.vstart = a.take<uint32_t>(nn);
     w.tile_hist = a.take<uint32_t>(tiles * VP_MAXBINS);
     w.unit_start = a.take<uint32_t>(nchunks * VP_MAXBINS);
-    w.unit_count = a.take<uint32_t>(nchunks * VP_MAXBINS);
+    w.batches = a.take<VoxelBatch>(nchunks * VP_MAXBINS);
+    w.nbatch = a.take<uint32_t>(nchunks + 1);
+    w.batch_prefix = a.take<uint32_t>(nchunks + 1);
+    w.over = a.take<VoxelOversize>(nchunks * VP_MAXBINS);
     const size_t off0 = a.off;
-    w.ticket = a.take<uint32_t>(4);
+    w.ticket = a.take<uint32_t>(64);                       // [0] ticket, [1] oversize units, [8..24) stamp sums (tuning builds)
+    w.nover = w.ticket + 1;
     w.status = a.take<uint64_t>(nchunks * VP_MAXBINS);
     w.clear_bytes = a.off - off0;
 }
@@ -637,6 +966,7 @@ extern "C" int pch_voxel_downsample_f64(const double* xyz, int64_t n, double vox
     g.nchunks = nchunks;
     g.tiles_per_chunk = ceil_div(chunk_size, VP_TILE);
     g.voxel = voxel_size;
+    g.rvoxel = 1.0 / voxel_size;
     g.bx = bits_for((uint64_t)gmeta[0] + 1);
     g.by = bits_for((uint64_t)gmeta[1] + 1);
     g.bz = bits_for((uint64_t)gmeta[2] + 1);
@@ -652,28 +982,52 @@ extern "C" int pch_voxel_downsample_f64(const double* xyz, int64_t n, double vox
     PCH_LAUNCH("voxel_tilehist", vx_tilehist_k, dim3(gt), dim3(VP_THREADS), 0, s, xyz, g, (const double*)w.minb,
                w.tile_hist);
     PCH_LAUNCH("voxel_binscan", vx_binscan_k, dim3((unsigned)nchunks), dim3(VP_MAXBINS), 0, s, g, w.tile_hist,
-               w.unit_start, w.unit_count);
+               w.unit_start, w.batches, w.nbatch, w.over, w.nover);
+    PCH_LAUNCH("voxel_batchscan", vx_batchscan_k, dim3(1), dim3(1024), 0, s, (const uint32_t*)w.nbatch, nchunks,
+               w.batch_prefix);
     PCH_LAUNCH("voxel_scatter", vx_scatter_k, dim3(gt), dim3(VP_THREADS), 0, s, xyz, g, (const double*)w.minb,
                (const uint32_t*)w.tile_hist, (const uint32_t*)w.unit_start, w.bufA);
-    // persistent finisher: two workgroups per CU draw the units in order
+    {   // units above the LDS capacity (dense columns): split by their next digit, one workgroup each
+        int64_t sg = nchunks * g.nb;
+        if (sg > 512) sg = 512;
+        PCH_LAUNCH("voxel_split", vx_split_k, dim3((unsigned)sg), dim3(1024), 0, s, g, (const double*)w.minb,
+                   (const Row*)w.bufA, w.batches, (const VoxelOversize*)w.over, (const uint32_t*)w.nover);
+    }
+    // persistent finisher: two 512-thread workgroups per CU draw the batches in order
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int64_t fg = (int64_t)cus * 2;
     if (fg > nchunks * g.nb) fg = nchunks * g.nb;
     const size_t shm = sizeof(VfShared);
-    if (g.rem + VF_ROWBITS <= 32) {
-        PCH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(vx_finish_k<uint32_t>),
+    static bool attr_set[PCH_MAX_DEVICES] = {};
+    const int slot = current_device_slot();
+    if (!attr_set[slot]) {
+        PCH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(vx_finish_k),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        PCH_LAUNCH("voxel_finish", vx_finish_k<uint32_t>, dim3((unsigned)fg), dim3(VP_THREADS), shm, s, g,
-                   (const double*)w.minb, (const uint32_t*)w.unit_start, (const uint32_t*)w.unit_count, w.bufA, w.bufB,
-                   w.vstart, w.status, w.ticket, out_idx, out_mean, out_count, out_chunk_offsets, out_m);
-    } else {
-        PCH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(vx_finish_k<unsigned long long>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        PCH_LAUNCH("voxel_finish", vx_finish_k<unsigned long long>, dim3((unsigned)fg), dim3(VP_THREADS), shm, s, g,
-                   (const double*)w.minb, (const uint32_t*)w.unit_start, (const uint32_t*)w.unit_count, w.bufA, w.bufB,
-                   w.vstart, w.status, w.ticket, out_idx, out_mean, out_count, out_chunk_offsets, out_m);
+        attr_set[slot] = true;
     }
+    PCH_LAUNCH("voxel_finish", vx_finish_k, dim3((unsigned)fg), dim3(VF_THREADS), shm, s, g,
+               (const double*)w.minb, (const VoxelBatch*)w.batches, (const uint32_t*)w.batch_prefix, w.bufA, w.bufB,
+               w.vstart, w.status, w.ticket, out_idx, out_mean, out_count, out_chunk_offsets, out_m,
+               reinterpret_cast<unsigned long long*>(w.ticket + 8));
+#ifdef PCH_VX_STAMPS
+    {
+        unsigned long long t[8];
+        uint32_t nb_tot = 0, nov = 0;
+        PCH_HIP_TRY(hipStreamSynchronize(s));
+        PCH_HIP_TRY(hipMemcpy(t, w.ticket + 8, sizeof(t), hipMemcpyDeviceToHost));
+        PCH_HIP_TRY(hipMemcpy(&nb_tot, w.batch_prefix + nchunks, 4, hipMemcpyDeviceToHost));
+        PCH_HIP_TRY(hipMemcpy(&nov, w.nover, 4, hipMemcpyDeviceToHost));
+        const char* nm[6] = {"ticket+lookup", "load+keys", "sort passes", "heads", "look-back", "reduce"};
+        fprintf(stderr, "voxel finisher: %u batches, %u oversize units; per-workgroup average (us):", nb_tot, nov);
+        for (int k = 0; k < 6; ++k) fprintf(stderr, "  %s %.1f", nm[k], (double)t[k] / 100.0 / (double)fg);
+        fprintf(stderr, "  | global-path batches %llu, empty slots %llu", t[6], t[7]);
+        unsigned long long polls = 0, wins = 0;
+        (void)hipMemcpyFromSymbol(&polls, HIP_SYMBOL(g_lb_polls), 8);
+        (void)hipMemcpyFromSymbol(&wins, HIP_SYMBOL(g_lb_windows), 8);
+        fprintf(stderr, "  | look-back totals so far: %llu windows, %llu failed polls\n", wins, polls);
+    }
+#endif
     return PCH_OK;
 }
 

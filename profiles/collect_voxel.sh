@@ -1,0 +1,15 @@
+#!/bin/bash
+# Voxel stage (BASELINE config 2 shape: 10 M float64 points, voxel 0.2 m, 500 000-row chunks):
+# kernel times and PMC traffic in three separate rocprofv3 runs.   bash profiles/collect_voxel.sh <tag>
+set -e -o pipefail
+tag=$1
+out=gpurun_out/prof_$tag
+mkdir -p $out
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 tools/voxel_probe.py 10000000 0.2 500000 > $out/stats.txt 2> $out/stats.err
+rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch --output-format csv -- python3 tools/voxel_probe.py 10000000 0.2 500000 > $out/fetch.txt 2> $out/fetch.err
+rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write --output-format csv -- python3 tools/voxel_probe.py 10000000 0.2 500000 > $out/write.txt 2> $out/write.err
+python3 profiles/summarize.py $tag $out/stats $out/pmc_fetch $out/pmc_write 10000000 voxel v0.2_chunk500k > $out/summary.txt
+cp $out/stats.txt profiles/${tag}_probe.txt
+rm -rf $out/stats $out/pmc_fetch $out/pmc_write
+echo "[collect_voxel $tag] done"
