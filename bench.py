@@ -26,35 +26,58 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 EPS, MIN_POINTS, CHUNK = 8.0, 80, 50000
 
 
-def knn_tile_bytes(points, eps, chunk):
-    """SURVEY.md 8(d) tile model for the radius-count kernel: cubic cells of side eps, every
-    query cell stages its <=27 occupied neighbour cells once (12 B/point) and writes one
-    4-byte word per point.  Returns (bytes, cell occupancy histogram summary)."""
+def _tile_sum(points, side, chunk, query_mask_fn=None):
+    """sum over (masked) query cells c of the points in the <=27 occupied cells around c, cells cubic of
+    side `side`, chunks kept apart.  Returns (sum, unique keys, counts, mask)."""
     import torch
     n = points.shape[0]
-    if n == 0:
-        return 0, {}
     lo = points.min(dim=0).values
-    c = torch.floor((points - lo).double() / eps).long()
-    dims = c.max(dim=0).values + 3
     ck = torch.arange(n, device=points.device) // chunk
+    c = torch.floor((points - lo).double() / side).long()
+    dims = c.max(dim=0).values + 3
     key = ((ck * dims[2] + c[:, 2] + 1) * dims[1] + c[:, 1] + 1) * dims[0] + c[:, 0] + 1
     uniq, cnt = torch.unique(key, return_counts=True)
+    mask = torch.ones_like(cnt, dtype=torch.bool) if query_mask_fn is None else query_mask_fn(cnt)
     total = torch.zeros((), dtype=torch.int64, device=points.device)
     for dz in (-1, 0, 1):
         for dy in (-1, 0, 1):
             for dx in (-1, 0, 1):
                 nk = uniq + (dz * dims[1] + dy) * dims[0] + dx
                 pos = torch.searchsorted(uniq, nk).clamp(max=uniq.numel() - 1)
-                hit = uniq[pos] == nk
+                hit = (uniq[pos] == nk) & mask
                 total += (cnt[pos] * hit).sum()
-    # occupancy histogram in power-of-two bins [2^k, 2^(k+1)) and the neighbour sum itself, so that the
-    # tile-model byte count can be recomputed: bytes = 12 * neighbour_points + 4 * points
+    return int(total), uniq, cnt, mask
+
+
+def knn_tile_bytes(points, eps, chunk, min_samples):
+    """Byte models of the radius-count kernel (db_core), both from SURVEY.md 8(d)'s tile formula
+    bytes = 12 * sum_c sum_{c' in N27(c), occupied} n_c' + 4 * N_f:
+
+    * all cells   - the formula as written: cubic cells of side eps, every query cell stages its 27 tiles;
+    * sparse path - the same formula on the kernel's OWN grid (side eps/sqrt(3): two points of a cell are
+                    neighbours by construction), summed over the query cells with fewer than min_samples
+                    points only.  A denser cell is core without a single distance test and moves nothing
+                    but its output; pricing its neighbour tiles is what pushed the round-1 fraction above 1
+                    on tower data.  The 27-block of such cells is what a sparse query cell stages before the
+                    early exit (every query at min_samples) normally ends the sweep.
+    Returns (bytes all cells, bytes sparse path, occupancy summary)."""
+    import torch
+    n = points.shape[0]
+    if n == 0:
+        return 0, 0, {}
+    total, uniq, cnt, _ = _tile_sum(points, eps, chunk)
+    side = eps / 3 ** 0.5 * (1.0 - 2.0 ** -16)
+    total_sparse, funiq, fcnt, fmask = _tile_sum(points, side, chunk, lambda c: c < min_samples)
+    # occupancy histogram in power-of-two bins [2^k, 2^(k+1)) and the neighbour sums themselves, so that the
+    # byte counts can be recomputed: bytes = 12 * neighbour_points + 4 * points
     bins = torch.floor(torch.log2(cnt.double())).long()
     hist = torch.bincount(bins).tolist()
     occ = dict(cells=int(uniq.numel()), max=int(cnt.max()), mean=float(cnt.double().mean()),
-               cell_side=eps, hist_log2=hist, neighbour_points=int(total), points=int(n))
-    return int(12 * int(total) + 4 * n), occ
+               cell_side=eps, hist_log2=hist, neighbour_points=int(total), points=int(n),
+               kernel_cell_side=side, kernel_cells=int(funiq.numel()), kernel_cells_sparse=int(fmask.sum()),
+               points_in_sparse_kernel_cells=int(fcnt[fmask].sum()),
+               neighbour_points_of_sparse_kernel_cells=int(total_sparse))
+    return int(12 * total + 4 * n), int(12 * total_sparse + 4 * n), occ
 
 
 def algorithmic_bytes(name, N, NF):
@@ -168,7 +191,7 @@ def main():
                      key=lambda r: -r[3])
     timed = {r[0] for r in kernels}
     gpu_ms = sum(r[3] for r in kernels) + sum(v for k, v in warm_ms.items() if k not in timed)
-    knn_bytes, occ = knn_tile_bytes(cl["ground"]["points"], EPS, CHUNK)
+    knn_bytes_all, knn_bytes, occ = knn_tile_bytes(cl["ground"]["points"], EPS, CHUNK, MIN_POINTS)
     dom = kernels[0]
 
     def roof(name, avg_ms):
@@ -186,11 +209,12 @@ def main():
     roofline = roof(dom[0], dom[1]) or dict(kernel=dom[0], bound="hbm", achieved=None,
                                             peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None)
     knn = next((roof(r[0], r[1]) for r in kernels if r[0] == "db_core"), None)
-    if knn:                                     # the same kernel priced at its compulsory floor
-        floor = 16 * NF
-        knn["achieved_compulsory_floor"] = round(floor / (knn["avg_ms"] * 1e-3) / 1e9, 1)
-        knn["note"] = ("tile-model bytes (SURVEY 8d); dense cells need no neighbour tiles, so the model "
-                       "over-credits this kernel on tower data - see achieved_compulsory_floor")
+    if knn:
+        knn["model"] = ("SURVEY 8d tile formula on the kernel's cell grid (side eps/sqrt(3)), summed over the query "
+                        "cells on the distance-test path (fewer than min_samples points); denser cells are core "
+                        "without a test and are priced at their output only")
+        knn["bytes_per_launch_all_cells"] = int(knn_bytes_all)
+        knn["frac_all_cells"] = round(knn_bytes_all / (knn["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     if roofline.get("kernel") == "mean_walk":
         roofline["note"] = ("largest kernel by time is the exact-centroid walk: a serial dependency chain on "
                             "3 wavefronts (latency-bound); see streaming_kernel for the largest HBM-bound kernel")
@@ -205,6 +229,7 @@ def main():
                 if r and tr and r["kernel"] in tr.get("kernels", {}):
                     r["traffic"] = tr["kernels"][r["kernel"]]
                     r["traffic_source"] = f"profiles/{tr.get('source')}_pmc_traffic.csv"
+                    r["frac_traffic"] = round(r["traffic"] / (r["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         except Exception:
             pass
 

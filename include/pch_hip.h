@@ -158,6 +158,16 @@ int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t min_samples,
                    int32_t* labels, uint8_t* core, int32_t* out_nclusters,
                    void* ws, size_t ws_bytes, void* stream);
 
+/* Relabels the result of the pch_dbscan_f32 call this thread made last, on the SAME workspace (which still
+ * holds the cell grid, the core flags and the sorted points): core points take map[old cluster id],
+ * every non-core point is assigned again as "smallest NEW id among its core neighbours within eps, else
+ * -1" (border points must be re-decided: the order of the ids may have changed).  Used by the cross-tile
+ * reconciliation (pointcloudhookup_amd/tiles.py): clusters cut by a tile edge are united and renumbered
+ * globally, which generalises the per-chunk label offsets of utils/tower_extraction.py:113-116.
+ * map [nmap] int32 (device): new id per old id (-1 = drop).  labels [n] int32: in/out. */
+int pch_dbscan_relabel_i32(const int32_t* map, int32_t nmap, int64_t n, int32_t* labels,
+                           void* ws, size_t ws_bytes, void* stream);
+
 /* First row of xyz [n,3] float32 that holds NaN or +-inf, -1 if every row is finite.
  * Replaces: sklearn's input validation inside DBSCAN.fit (check_array, ensure_all_finite), which
  * is what makes a chunk "fail" in the reference (utils/tower_extraction.py:107-119).

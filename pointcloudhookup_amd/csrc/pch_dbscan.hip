@@ -22,7 +22,7 @@ constexpr int DB_WAVES   = DB_THREADS / 64;
 constexpr int DB_ROWS    = 25;
 constexpr int INT_BIG    = 0x7fffffff;
 constexpr int DB_FEW_QUERIES = 24;
-constexpr int DB_SEGS = 43;          // 9 inner + 9 + 9 end pieces of the near runs + 16 outer runs   // below: candidate-parallel radius count, else query-parallel tiles
+constexpr int DB_SEGS = 43;          // 9 inner + 9 + 9 end pieces of the near runs + 16 outer runs
 
 struct DbGrid {
     float   ox, oy, oz;          // grid origin (lower corner of the bounding box)
@@ -1195,6 +1195,33 @@ __global__ __launch_bounds__(DB_THREADS) void db_border_k(DbGrid g, const float4
     }
 }
 
+// ---- relabelling with an external cluster map (cross-tile reconciliation, tiles.py): core points and
+// cells take map[old id], every other point goes back to -1 and is assigned again by db_border_k, so
+// that a border point takes the smallest NEW id among its core neighbours
+__global__ __launch_bounds__(DB_THREADS) void db_remap_points_k(const float4* __restrict__ pts,
+                                                                const uint8_t* __restrict__ core_s, int64_t n,
+                                                                const int32_t* __restrict__ map, int32_t nmap,
+                                                                int32_t* __restrict__ labels) {
+    const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t o = __float_as_uint(pts[i].w);
+    int32_t lab = -1;
+    if (core_s[i]) {
+        const int32_t old = labels[o];
+        lab = (old >= 0 && old < nmap) ? map[old] : -1;
+    }
+    labels[o] = lab;
+}
+__global__ __launch_bounds__(DB_THREADS) void db_remap_cells_k(int* __restrict__ cell_label,
+                                                               const uint32_t* __restrict__ cell_ncore, int m,
+                                                               const int32_t* __restrict__ map, int32_t nmap) {
+    const int c = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (c >= m) return;
+    if (cell_ncore[c] == 0) return;
+    const int old = cell_label[c];
+    cell_label[c] = (old >= 0 && old < nmap) ? map[old] : INT_BIG;
+}
+
 __global__ void db_finish_k(const uint32_t* __restrict__ total, int32_t* __restrict__ out_nclusters) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *out_nclusters = (int32_t)*total;
 }
@@ -1260,6 +1287,10 @@ static int db_sort_mode() {
     }
     return m;
 }
+
+// what pch_dbscan_relabel_i32 needs to know about the run whose workspace it continues
+struct DbLastRun { void* ws; size_t ws_bytes; int64_t n; int m; DbGrid g; bool has_rowtab; };
+static thread_local DbLastRun g_last = {nullptr, 0, 0, 0, {}, false};
 
 // host mirror of f32_unordered
 static float host_unordered(uint32_t k) {
@@ -1471,6 +1502,36 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
                (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, (const uint8_t*)w.core_s,
                (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, (const int*)w.cell_label, labels);
     if (k_host) PCH_TRY(peek_wait(k_host, sizeof(int32_t)));
+    g_last.ws = ws; g_last.ws_bytes = ws_bytes; g_last.n = n; g_last.m = m; g_last.g = g;
+    g_last.has_rowtab = rowtab != nullptr;
+    return PCH_OK;
+}
+
+extern "C" int pch_dbscan_relabel_i32(const int32_t* map, int32_t nmap, int64_t n, int32_t* labels, void* ws,
+                                      size_t ws_bytes, void* stream) {
+    PCH_DEVICE_GUARD(labels);
+    hipStream_t s = (hipStream_t)stream;
+    PCH_REQUIRE(n >= 0 && nmap >= 0 && (nmap == 0 || map) && (n == 0 || labels), "bad argument");
+    if (n == 0) return PCH_OK;
+    if (g_last.ws != ws || g_last.ws_bytes != ws_bytes || g_last.n != n || ws == nullptr) {
+        set_error("pch_dbscan_relabel_i32 must follow pch_dbscan_f32 of this thread on the same, untouched workspace");
+        return PCH_ERR_ARG;
+    }
+    Arena a(ws, ws_bytes);
+    DbWs w;
+    db_plan(a, n, w);
+    const DbGrid g = g_last.g;
+    const int m = g_last.m;
+    const unsigned gn = (unsigned)ceil_div(n, DB_THREADS);
+    const unsigned gc = (unsigned)ceil_div(m, DB_WAVES);
+    PCH_LAUNCH("db_remap_points", db_remap_points_k, dim3(gn), dim3(DB_THREADS), 0, s, (const float4*)w.pts,
+               (const uint8_t*)w.core_s, n, map, nmap, labels);
+    PCH_LAUNCH("db_remap_cells", db_remap_cells_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
+               w.cell_label, (const uint32_t*)w.cell_ncore, m, map, nmap);
+    PCH_LAUNCH("db_border", db_border_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
+               (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m,
+               g_last.has_rowtab ? (const int2*)w.rowtab : (const int2*)nullptr, (const uint8_t*)w.core_s,
+               (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, (const int*)w.cell_label, labels);
     return PCH_OK;
 }
 

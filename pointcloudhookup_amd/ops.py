@@ -229,6 +229,24 @@ def dbscan(xyz, eps=8.0, min_samples=80, chunk_size=50000, aabb=None, want_core=
     return labels, core, k
 
 
+def dbscan_relabel(labels, cluster_map):
+    """Continues the LAST ops.dbscan call of this thread (its workspace still holds the grid): core
+    points take cluster_map[old id], border points are decided again as the smallest new id among
+    their core neighbours.  labels int32 [n] is updated in place and returned."""
+    L = _lib.lib()
+    labels = _need_cuda(labels, torch.int32, "labels")
+    cmap = _need_cuda(cluster_map, torch.int32, "cluster_map")
+    dev = labels.device
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ws = getattr(_tls, "ws", {}).get(key)
+    if ws is None:
+        raise RuntimeError("dbscan_relabel must follow ops.dbscan on this thread")
+    with torch.cuda.device(dev):
+        _lib.check(L.pch_dbscan_relabel_i32(_ptr(cmap), cmap.numel(), labels.numel(), _ptr(labels), _ptr(ws),
+                                            ws.numel(), _stream()))
+    return labels
+
+
 def set_dbscan_sort_mode(mode):
     """Cell sort of ops.dbscan: "auto" (by chunk count), "chunk" (one workgroup per chunk) or "global"
     (one radix sort).  Same results either way; tests compare them."""
