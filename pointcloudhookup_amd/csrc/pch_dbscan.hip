@@ -1219,7 +1219,8 @@ __global__ __launch_bounds__(DB_THREADS) void db_remap_cells_k(int* __restrict__
     if (c >= m) return;
     if (cell_ncore[c] == 0) return;
     const int old = cell_label[c];
-    cell_label[c] = (old >= 0 && old < nmap) ? map[old] : INT_BIG;
+    const int neu = (old >= 0 && old < nmap) ? map[old] : -1;
+    cell_label[c] = neu >= 0 ? neu : INT_BIG;              // a dropped cluster attracts no border points
 }
 
 __global__ void db_finish_k(const uint32_t* __restrict__ total, int32_t* __restrict__ out_nclusters) {

@@ -13,6 +13,14 @@ exchange makes the result global:
 
 Traffic is a few KB per rank (RCCL over xGMI when the tensors live on the GPUs, gloo on CPU
 tensors in the tests): latency bound, one collective each, no bulk data ever moves.
+
+Second mode (BASELINE config 4): ONE cloud cut into x-tiles, one per
+rank, every tile extended by a 2*eps halo, clustered globally (no 50 000-row chunks).  A tower cut
+by a tile edge must come out as ONE cluster with the id a single-GPU run over the whole cloud
+gives it: ``cluster_tiled`` below - local exact DBSCAN per tile, one all_gather of the
+(global row, local cluster) pairs of the core points near the tile edges, the same union-find on
+every rank, then a relabel pass on the device (``ops.dbscan_relabel``) that also re-decides the
+border points under the new numbering.
 """
 from __future__ import annotations
 
@@ -90,3 +98,135 @@ def dedup_centres(centres, threshold=30.0):
         if all(np.linalg.norm(c[i] - c[j]) >= threshold for j in kept):
             kept.append(i)
     return kept
+
+
+# ------------------------------------------------------------------------------------------------
+# x-tiles with a halo: one cloud, clustered as a whole across the ranks
+def tile_edges(xmin, xmax, world):
+    """world+1 edges of equal-width x-tiles; tile r owns [edges[r], edges[r+1]) (the last one also xmax)."""
+    return np.linspace(float(xmin), float(xmax), int(world) + 1)
+
+
+def tile_select(x, edges, rank, halo):
+    """(rows in this rank's tile incl. halo, owned flag per selected row) for coordinates x (numpy or
+    torch 1-D).  Works on any array type with boolean masks."""
+    lo, hi = float(edges[rank]), float(edges[rank + 1])
+    last = rank == len(edges) - 2
+    take = (x >= lo - halo) & ((x < hi + halo) | (last & (x <= hi + halo)))
+    own = (x >= lo) & ((x < hi) | (last & (x <= hi)))
+    return take, own
+
+
+class HipFit:
+    """Local clustering on the GPU: exact global DBSCAN of one tile + relabelling on the retained grid."""
+
+    def __init__(self, eps, min_samples):
+        self.eps, self.min_samples = float(eps), int(min_samples)
+        self.labels = None
+
+    def fit(self, points):
+        from . import ops
+        self.labels, core, k = ops.dbscan(points, self.eps, self.min_samples, 0, want_core=True)
+        return self.labels, core.bool(), k
+
+    def relabel(self, cluster_map):
+        from . import ops
+        cmap = torch.as_tensor(cluster_map, dtype=torch.int32, device=self.labels.device)
+        return ops.dbscan_relabel(self.labels, cmap)
+
+
+def _gather_rows(t, group):
+    """all_gather of a [k, C] int64 tensor whose k differs per rank.  Returns list of per-rank tensors."""
+    world = dist.get_world_size(group)
+    cnt = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt, group=group)
+    counts = [int(c.item()) for c in counts]
+    kmax = max(max(counts), 1)
+    padded = torch.zeros((kmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    padded[: t.shape[0]] = t
+    out = [torch.zeros_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded, group=group)
+    return [o[:c] for o, c in zip(out, counts)]
+
+
+def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fit=None, group=None):
+    """Global DBSCAN of a cloud that is spread over the ranks as x-tiles with a halo of at least 2*eps.
+
+    points : [n,3] float32 points of THIS rank's tile, halo included (device tensor for the HIP fit)
+    rows   : [n] int64 global row of every point (its index in the whole cloud; defines the cluster numbering)
+    own    : [n] bool, True for the points this rank reports (x inside its own tile)
+    x_lo, x_hi : this rank's own x-range [x_lo, x_hi)
+    halo   : width of the overlap on either side (default and minimum 2*eps); every rank must use the same
+    Returns (labels int32 [n] for ALL local points (valid where ``own``), number of global clusters).
+
+    Result for the owned points = one DBSCAN(eps, min_samples) over the whole cloud, ids = rank of the
+    cluster's smallest core row (sklearn's numbering).  Why it is exact: a point's core flag is exact when
+    its eps-ball lies inside the tile, i.e. for x in [x_lo - eps, x_hi + eps) with a 2*eps halo; flags in the
+    outer ring can only be false negatives.  So local clusters are sound pieces of the true clusters, every
+    true core-core edge is seen whole by the tile that owns one endpoint, and pieces that share a core
+    point (same global row, seen by two tiles) belong together.  Border points are re-decided after the
+    renumbering on the device (their core neighbours all have exact flags)."""
+    fit = fit or HipFit(eps, min_samples)
+    labels, core, k = fit.fit(points)
+    k = int(k)
+    single = not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1
+    rows_h = torch.as_tensor(rows).cpu().to(torch.int64)
+    lab_h = torch.as_tensor(labels).cpu().to(torch.int64)
+    core_h = torch.as_tensor(core).cpu().bool()
+    x_h = torch.as_tensor(points)[:, 0].cpu()
+    # smallest global core row of every local cluster
+    minrow = torch.full((max(k, 1),), torch.iinfo(torch.int64).max, dtype=torch.int64)
+    cm = core_h & (lab_h >= 0)
+    if cm.any():
+        minrow.scatter_reduce_(0, lab_h[cm], rows_h[cm], reduce="amin")
+    minrow = minrow[:k]
+    if single:
+        order = torch.argsort(minrow)
+        cmap = torch.empty(k, dtype=torch.int64)
+        cmap[order] = torch.arange(k)
+        return fit.relabel(cmap.to(torch.int32)), k
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    comm_dev = torch.device("cpu")
+    if dist.get_backend(group) == "nccl":                 # RCCL moves device buffers (a few KB..MB over xGMI)
+        comm_dev = torch.as_tensor(points).device
+    # core points that another tile also holds: everything outside [x_lo + halo, x_hi - halo)
+    halo = 2.0 * float(eps) if halo is None else float(halo)
+    if halo < 2.0 * float(eps):
+        raise ValueError("halo must be at least 2*eps")
+    edge = cm & ((x_h < float(x_lo) + halo) | (x_h >= float(x_hi) - halo))
+    pairs = torch.stack([rows_h[edge], lab_h[edge]], dim=1)           # (global row, LOCAL cluster id)
+    all_minrow = _gather_rows(minrow.reshape(-1, 1).to(comm_dev), group)
+    all_pairs = _gather_rows(pairs.to(comm_dev), group)
+    counts = [int(m.shape[0]) for m in all_minrow]
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    total = int(offs[-1])
+    if total == 0:
+        return fit.relabel(torch.zeros(0, dtype=torch.int32)), 0
+    # union-find over all local clusters (uid = rank offset + local id): pieces sharing a core row are one cluster
+    parent = np.arange(total)
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
+    pr = torch.cat([torch.stack([p[:, 0], p[:, 1] + int(offs[r])], dim=1) for r, p in enumerate(all_pairs)]).cpu().numpy()
+    if len(pr):
+        pr = pr[np.lexsort((pr[:, 1], pr[:, 0]))]
+        same = np.flatnonzero(pr[1:, 0] == pr[:-1, 0])
+        for i in same:
+            a, b = find(int(pr[i, 1])), find(int(pr[i + 1, 1]))
+            if a != b:
+                parent[max(a, b)] = min(a, b)
+    root = np.array([find(i) for i in range(total)])
+    mr = torch.cat([m.reshape(-1) for m in all_minrow]).cpu().numpy()
+    comp_min = np.full(total, np.iinfo(np.int64).max)
+    np.minimum.at(comp_min, root, mr)
+    roots = np.flatnonzero(root == np.arange(total))
+    roots = roots[np.argsort(comp_min[roots], kind="stable")]          # numbered by smallest core row
+    gid = np.full(total, -1, np.int64)
+    gid[roots] = np.arange(len(roots))
+    cmap = gid[root[offs[rank]:offs[rank] + k]]
+    return fit.relabel(torch.as_tensor(cmap, dtype=torch.int32)), int(len(roots))

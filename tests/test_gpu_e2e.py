@@ -221,3 +221,29 @@ def test_tower_clusters_equals_the_three_stage_calls(cuda):
     check(ops.tower_clusters(raw, want_index=True, k_cap=1))        # more clusters than k_cap
     g, l, kk, p, o, s = ops.tower_clusters(raw, segment=False)
     assert p is None and kk == k and torch.equal(l, labels)
+
+
+# ------------------------------------------------------------------ BASELINE config 4: x-tiles + halo
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_cluster_tiled_hip_equals_global_dbscan(cuda, oracle_clib, tmp_path, world):
+    """The tiled clustering of tests/test_host.py with the HIP kernels doing the local fit and the
+    relabel pass (pch_dbscan_f32 + pch_dbscan_relabel_i32), `world` processes sharing this GPU, the
+    exchange over gloo.  Towers and a thin bridge sit on the tile edges; every rank's labels must equal
+    one DBSCAN over the whole cloud."""
+    from test_host import _run_tiled
+    _run_tiled(tmp_path, world, "gpu", 29751 + world)
+
+
+def test_dbscan_relabel_redecides_border_points(cuda, oracle_clib):
+    """Swapping the ids of two clusters must move a border point that touches both to the other one."""
+    a = np.column_stack([np.linspace(0, 1, 30), np.zeros(30), np.zeros(30)])
+    b = np.column_stack([np.linspace(3.2, 4.2, 30), np.zeros(30), np.zeros(30)])
+    X = np.vstack([b, [[2.1, 0, 0]], a]).astype(np.float32)            # the tie fixture: point 30 touches both
+    dev = torch.from_numpy(X).to(cuda)
+    labels, core, k = ops.dbscan(dev, 1.15, 8, 0, want_core=True)
+    assert k == 2 and int(labels[30]) == 0 and not bool(core[30])
+    swapped = ops.dbscan_relabel(labels, torch.tensor([1, 0], dtype=torch.int32, device=cuda)).cpu().numpy()
+    assert (swapped[:30] == 1).all() and (swapped[31:] == 0).all()
+    assert swapped[30] == 0                                            # smallest NEW id among its core neighbours
+    dropped = ops.dbscan_relabel(labels, torch.tensor([5, -1], dtype=torch.int32, device=cuda)).cpu().numpy()
+    assert (dropped[:30] == -1).all() and (dropped[31:] == 5).all() and dropped[30] == 5

@@ -284,3 +284,103 @@ def test_obb_worker_processes_return_the_serial_results():
             np.testing.assert_array_equal(b0[0], b1[0])
             np.testing.assert_array_equal(b0[1], b1[1])
     assert serial[2][1] is not None
+
+
+# ------------------------------------------------------------------ x-tiles with a halo (BASELINE config 4)
+_TILED_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from pointcloudhookup_amd import tiles
+from oracle import dbscan as odb                      # the checker (tests only)
+rank, world, local = tiles.init_from_env(backend="gloo")
+use_gpu = sys.argv[2] == "gpu"
+EPS, MS = 8.0, 40
+
+def cloud():
+    rng = np.random.default_rng(4242)
+    L = 600.0
+    edges = tiles.tile_edges(0.0, L, world)
+    parts = []
+    for cx in list(edges[1:-1]) + [edges[1] - 30.0, 37.0, L - 21.0]:      # towers ON every inner edge + elsewhere
+        parts.append(rng.normal([cx, 50.0, 20.0], [2.5, 2.5, 8.0], (700, 3)))
+    parts.append(np.column_stack([rng.uniform(0, L, 1500), rng.uniform(0, 100, 1500), rng.uniform(0, 40, 1500)]))
+    # a thin bridge of core points along x that crosses an edge, and sparse border material around it
+    bx = np.linspace(edges[1] - 40.0, edges[1] + 40.0, 900)
+    parts.append(np.column_stack([bx, np.full_like(bx, 80.0), np.full_like(bx, 5.0)]) + rng.normal(0, 0.3, (900, 3)))
+    X = np.vstack(parts).astype(np.float32)
+    return X[rng.permutation(len(X))], edges
+
+X, edges = cloud()
+
+class OracleFit:                                       # CPU stand-in for tiles.HipFit (tests only)
+    def fit(self, pts):
+        self.pts = np.asarray(pts, np.float32)
+        self.labels, self.core = odb.dbscan_fit_c(self.pts, EPS, MS)
+        k = int(self.labels.max()) + 1 if (self.labels >= 0).any() else 0
+        return torch.from_numpy(self.labels.astype(np.int32)), torch.from_numpy(self.core.astype(bool)), k
+    def relabel(self, cmap):
+        cmap = np.asarray(cmap, np.int64)
+        new = np.full(len(self.pts), -1, np.int64)
+        c = self.core.astype(bool)
+        new[c] = cmap[self.labels[c]]
+        P = self.pts.astype(np.float64)
+        for i in np.flatnonzero(~c):
+            d = ((P[c] - P[i]) ** 2)
+            near = (d[:, 0] + d[:, 1] + d[:, 2]) <= EPS * EPS
+            if near.any():
+                new[i] = new[c][near].min()
+        return torch.from_numpy(new.astype(np.int32))
+
+take, own = tiles.tile_select(X[:, 0], edges, rank, 2 * EPS)
+rows = np.flatnonzero(take)
+pts = X[rows]
+if use_gpu:
+    dev = torch.device("cuda:0")
+    labels, K = tiles.cluster_tiled(torch.from_numpy(pts).to(dev), torch.from_numpy(rows), own[rows],
+                                    edges[rank], edges[rank + 1], EPS, MS)
+    labels = labels.cpu().numpy()
+else:
+    labels, K = tiles.cluster_tiled(torch.from_numpy(pts), torch.from_numpy(rows), own[rows],
+                                    edges[rank], edges[rank + 1], EPS, MS, fit=OracleFit())
+    labels = labels.numpy()
+want, _ = odb.dbscan_fit_c(X, EPS, MS)                 # one DBSCAN over the whole cloud
+o = own[rows]
+assert K == want.max() + 1, (K, want.max() + 1)
+assert np.array_equal(labels[o], want[rows[o]]), np.flatnonzero(labels[o] != want[rows[o]])[:10]
+# the towers on the inner edges really are cut by the tiling: some cluster has owned points on both sides
+if world > 1 and rank == 0:
+    side = np.searchsorted(edges, X[:, 0], side="right") - 1
+    cut = [c for c in range(K) if len(set(side[want == c])) > 1]
+    assert len(cut) >= world - 1, cut
+got = torch.zeros(len(X), dtype=torch.int64) - 7
+got[torch.from_numpy(rows[o])] = torch.from_numpy(labels[o].astype(np.int64))
+if world > 1:
+    parts = [torch.zeros_like(got) for _ in range(world)]
+    dist.all_gather(parts, got)
+    full = torch.stack(parts).max(dim=0).values.numpy()
+    assert np.array_equal(full, want)                  # every point owned exactly once, labels global
+    dist.barrier()
+    dist.destroy_process_group()
+print("rank", rank, "ok", K)
+'''
+
+
+def _run_tiled(tmp_path, world, mode, port):
+    script = tmp_path / f"tiled_{world}.py"
+    script.write_text(_TILED_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, mode], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_cluster_tiled_equals_global_dbscan_gloo(tmp_path, oracle_clib, world):
+    """x-tiles with a 2*eps halo, towers and a thin bridge cut by the tile edges: the labels every rank reports
+    for its own points equal ONE DBSCAN over the whole cloud (exchange and union-find over gloo; the local
+    fit is the CPU oracle here, the HIP kernels in tests/test_gpu_e2e.py)."""
+    _run_tiled(tmp_path, world, "cpu", 29741 + world)
