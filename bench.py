@@ -115,6 +115,9 @@ def main():
                     help="skip the two-tiles-in-flight side measurement (profiling runs)")
     ap.add_argument("--no-side", action="store_true",
                     help="skip every side measurement (voxel stage, other workloads): profiling runs")
+    ap.add_argument("--las", default=None,
+                    help="BASELINE config 5: a real .las file run end to end through the drop-in modules "
+                         "(voxel downsample -> extract_towers); reported as a side value, 'skipped' without a file")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -255,8 +258,46 @@ def main():
         "knn_cell_occupancy": occ,
     }
 
-    # ---- BASELINE config 2 side measurement: the voxel stage on 10 M float64 points (not in `value`)
+    # ---- side measurements (none of them in `value`)
     if world == 1 and not args.no_side:
+        def timed_steps(tile, k):
+            pipeline.cluster_points(tile, EPS, MIN_POINTS, CHUNK)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                c2 = pipeline.cluster_points(tile, EPS, MIN_POINTS, CHUNK)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / k, c2
+
+        # the other workloads of SURVEY 8d on the same harness: the local (zero-offset) frame and the uniform cloud
+        others = {}
+        for kind, frame in (("corridor", "local" if args.frame == "offset" else "offset"), ("uniform", args.frame)):
+            if kind == args.kind and frame == args.frame:
+                continue
+            try:
+                tile = synth.corridor_torch(N, seed=seed, kind=kind, offset=(frame == "offset"), device=dev,
+                                            dtype=torch.float32)
+                dt2, c2 = timed_steps(tile, 3)
+                others[f"{kind}/{frame}"] = {"ms_per_step": round(dt2 * 1e3, 3), "Mpts_per_s": round(N / dt2 / 1e6, 1),
+                                             "filtered_points": int(c2["ground"]["count"]), "clusters": int(c2["nclusters"])}
+                del tile, c2
+            except Exception as e:
+                others[f"{kind}/{frame}"] = {"error": str(e)}
+        out["other_workloads"] = others
+
+        # stage D1-D3 on the clusters of the timed tile (host: per-cluster oriented boxes; SURVEY 8f "next")
+        try:
+            os.environ.setdefault("PCH_OBB_WORKERS", str(min(16, os.cpu_count() or 1)))
+            t0 = time.perf_counter()
+            towers = pipeline.tower_table(cl)
+            out["tower_table"] = {"ms": round((time.perf_counter() - t0) * 1e3, 1), "clusters": K,
+                                  "towers": len(towers), "obb_workers": int(os.environ["PCH_OBB_WORKERS"]),
+                                  "note": "host stage D1-D3 (qhull boxes in worker processes), outside the timed region"}
+        except Exception as e:
+            out["tower_table"] = {"error": str(e)}
+
+        # BASELINE config 2: the voxel stage on 10 M float64 points, and the drop-ins end to end on a LAS file
+        # of that cloud (LAS in -> voxel LAS out -> tower dicts out, wall clock incl. file I/O)
         try:
             nv = 10_000_000
             xyz64 = synth.corridor_torch(nv, seed=synth.SEED0 + 1, kind="corridor", offset=True, device=dev)
@@ -269,9 +310,61 @@ def main():
             dtv = (time.perf_counter() - t0) / 3
             out["voxel_stage"] = {"points": nv, "voxel": 0.2, "chunk": 500000, "voxels_out": int(vi.shape[0]),
                                   "ms": round(dtv * 1e3, 3), "Mpts_per_s": round(nv / dtv / 1e6, 1)}
-            del xyz64, vi, vm, vc, vo
+            del vi, vm, vc, vo
+            import tempfile
+            from pointcloudhookup_amd import las as _las
+            from pointcloudhookup_amd.ui import import_PC as _imp
+            from pointcloudhookup_amd.utils import tower_extraction as _te
+            with tempfile.TemporaryDirectory(prefix="pch_bench_") as td:
+                sc, of = np.array([0.001, 0.001, 0.001]), np.array([437000.0, 3139000.0, 0.0])
+                src = os.path.join(td, "cloud.las")
+                _las.write_device(src, _las.LasHeader(point_format=3, version=(1, 2), scales=sc, offsets=of),
+                                  ops.las_unscale(xyz64, sc, of))
+                del xyz64
+                cwd = os.getcwd()
+                os.chdir(td)
+                try:
+                    t0 = time.perf_counter()
+                    _imp.run_voxel_downsampling(src, os.path.join(td, "output", "point_2.las"), 0.2, 500000)
+                    t1 = time.perf_counter()
+                    tw = _te.extract_towers(os.path.join(td, "output", "point_2.las"), log_callback=lambda m: None)
+                    t2 = time.perf_counter()
+                finally:
+                    os.chdir(cwd)
+                out["dropin_end_to_end"] = {"points": nv, "run_voxel_downsampling_s": round(t1 - t0, 3),
+                                            "extract_towers_s": round(t2 - t1, 3), "towers": len(tw),
+                                            "note": "wall clock, LAS files in and out (config 2 cloud)"}
         except Exception as e:
-            out["voxel_stage"] = {"error": str(e)}
+            out.setdefault("voxel_stage", {"error": str(e)})
+            out["dropin_end_to_end"] = {"error": str(e)}
+
+    # ---- BASELINE config 5: a real .las through the drop-ins
+    if world == 1:
+        if args.las and os.path.exists(args.las):
+            try:
+                import tempfile
+                from pointcloudhookup_amd.ui import import_PC as _imp
+                from pointcloudhookup_amd.utils import tower_extraction as _te
+                with tempfile.TemporaryDirectory(prefix="pch_cfg5_") as td:
+                    cwd = os.getcwd()
+                    os.chdir(td)
+                    try:
+                        t0 = time.perf_counter()
+                        _imp.run_voxel_downsampling(os.path.abspath(args.las) if os.path.isabs(args.las)
+                                                    else os.path.join(cwd, args.las),
+                                                    os.path.join(td, "output", "point_2.las"), 0.1, 500000)
+                        t1 = time.perf_counter()
+                        tw = _te.extract_towers(os.path.join(td, "output", "point_2.las"), log_callback=lambda m: None)
+                        t2 = time.perf_counter()
+                    finally:
+                        os.chdir(cwd)
+                out["config5_real_las"] = {"file": args.las, "run_voxel_downsampling_s": round(t1 - t0, 3),
+                                           "extract_towers_s": round(t2 - t1, 3), "towers": len(tw)}
+            except Exception as e:
+                out["config5_real_las"] = {"file": args.las, "error": str(e)}
+        else:
+            out["config5_real_las"] = {"skipped": "no file" if not args.las else f"no file at {args.las}",
+                                       "note": "the reference ships no .las sample; pass --las PATH"}
 
     # ---- tile stream side measurement (not in `value`): two host threads, each with its own HIP
     # stream and workspace, work through tiles at the same time - one tile's latency-bound

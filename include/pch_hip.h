@@ -68,6 +68,33 @@ int pch_voxel_downsample_f64(const double* xyz, int64_t n, double voxel_size,
                              int64_t* out_chunk_offsets, int64_t* out_m,
                              void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------ LAS files (native reader / writer)
+ * What laspy does for the reference on the hot path, done by the library itself (host C++ + one decode
+ * kernel): read the public header block; read the X, Y, Z integers of a record range straight into a
+ * DEVICE buffer (memory-mapped file -> pinned double buffer -> H2D copy overlapped with the decode);
+ * write a LAS file whose records carry X, Y, Z and zeros elsewhere (what laspy writes for a LasData whose
+ * only assigned dimensions are x, y, z).  LAS 1.0-1.4, point formats 0-10, uncompressed; VLRs, extra bytes
+ * and padding in front of the point data are skipped through header_size / offset_to_points /
+ * record_length.
+ * Replaces: laspy.read(...) / laspy.open(...).read() (ui/import_PC.py:28, utils/tower_extraction.py:60-61,
+ *           ui/extract.py:114-115); LasHeader / LasData(...).write (ui/import_PC.py:35-42,64-65,
+ *           utils/tower_extraction.py:243-257).  Both synchronise `stream` before returning. */
+typedef struct PchLasHeader {
+    uint8_t  version_major, version_minor, point_format, reserved0;
+    uint16_t header_size, record_length;
+    uint32_t offset_to_points, num_vlrs;
+    uint64_t point_count;
+    double   scales[3], offsets[3], mins[3], maxs[3];
+} PchLasHeader;
+int    pch_las_read_header(const char* path_host, PchLasHeader* out_host);
+size_t pch_las_read_ws_bytes(void);
+/* out_XYZ [count,3] int32 (device): records first .. first+count-1;  ws: device scratch */
+int    pch_las_read_xyz_i32(const char* path_host, int64_t first, int64_t count, int32_t* out_XYZ,
+                            void* ws, size_t ws_bytes, void* stream);
+/* hdr_host: point_format, version, scales, offsets are used; XYZ [n,3] int32 (device) */
+int    pch_las_write_xyz_i32(const char* path_host, const PchLasHeader* hdr_host, const int32_t* XYZ,
+                             int64_t n, void* stream);
+
 /* LAS point records -> X,Y,Z: gathers the three little-endian int32 at the start of every
  * `record_len`-byte record (LAS 1.0-1.4 point formats 0-10 all start with X,Y,Z).
  * Replaces: laspy's record parsing behind las.X/.Y/.Z (ui/import_PC.py:28,

@@ -31,6 +31,10 @@ _SIGS = {
     "pch_device_count": (C.c_int, []),
     "pch_voxel_downsample_ws_bytes": (_sz, [_i64, _i64]),
     "pch_voxel_downsample_f64": (C.c_int, [_vp, _i64, _f64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pch_las_read_header": (C.c_int, [C.c_char_p, _vp]),
+    "pch_las_read_ws_bytes": (_sz, []),
+    "pch_las_read_xyz_i32": (C.c_int, [C.c_char_p, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "pch_las_write_xyz_i32": (C.c_int, [C.c_char_p, _vp, _vp, _i64, _vp]),
     "pch_las_records_xyz_i32": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "pch_las_scale_i32_f64": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "pch_las_unscale_f64_i32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
@@ -58,6 +62,15 @@ _SIGS = {
     "pch_get_profile": (C.c_int, [C.c_int, _vp, _vp, _vp]),
 }
 
+
+
+class LasHeaderC(C.Structure):
+    """PchLasHeader (include/pch_hip.h)."""
+    _fields_ = [("version_major", C.c_uint8), ("version_minor", C.c_uint8), ("point_format", C.c_uint8),
+                ("reserved0", C.c_uint8), ("header_size", C.c_uint16), ("record_length", C.c_uint16),
+                ("offset_to_points", C.c_uint32), ("num_vlrs", C.c_uint32), ("point_count", C.c_uint64),
+                ("scales", C.c_double * 3), ("offsets", C.c_double * 3), ("mins", C.c_double * 3),
+                ("maxs", C.c_double * 3)]
 
 
 class TowerClustersInfo(C.Structure):

@@ -101,27 +101,61 @@ def read(path):
     return LasData(hdr, XYZ)
 
 
-def read_device(path, device):
-    """Header + X,Y,Z decoded ON THE DEVICE: the raw record bytes are copied to the GPU as they
-    lie in the file (memory mapped, no host-side strided gather) and ``ops.las_records_xyz`` picks
-    the three int32 of every record.  Returns (LasHeader, int32 [n,3] device tensor)."""
-    import torch
-    from . import ops
+def read_header_native(path):
+    """The public header block as parsed by libpch_hip.so (pch_las_read_header); needs no GPU."""
+    import ctypes as C
+    from . import _lib
     if not os.path.exists(path):
         raise FileNotFoundError(path)
-    hdr = read_header(path)
-    n, rl = hdr.point_count, hdr.record_length
-    if n == 0:
-        return hdr, torch.zeros((0, 3), dtype=torch.int32, device=device)
-    mm = np.memmap(path, dtype=np.uint8, mode="r", offset=hdr.offset_to_points, shape=(n * rl,))
+    h = _lib.LasHeaderC()
+    _lib.check(_lib.lib().pch_las_read_header(os.fsencode(path), C.addressof(h)))
+    return LasHeader(point_format=int(h.point_format), version=(int(h.version_major), int(h.version_minor)),
+                     scales=np.array(h.scales), offsets=np.array(h.offsets), point_count=int(h.point_count),
+                     record_length=int(h.record_length), offset_to_points=int(h.offset_to_points),
+                     header_size=int(h.header_size), mins=np.array(h.mins), maxs=np.array(h.maxs))
+
+
+def read_device(path, device):
+    """Header + X,Y,Z ON THE DEVICE, read by the library itself (pch_las_read_xyz_i32): the file is memory
+    mapped, its point records travel through a pinned double buffer and are decoded by a kernel while
+    the next hop is copied.  Returns (LasHeader, int32 [n,3] device tensor)."""
+    import torch
+    from . import _lib, ops
+    hdr = read_header_native(path)
+    n = hdr.point_count
     out = torch.empty((n, 3), dtype=torch.int32, device=device)
-    step = max(1, (256 << 20) // rl)                      # ~256 MiB of records per hop
-    for s in range(0, n, step):
-        e = min(n, s + step)
-        rec = torch.from_numpy(np.array(mm[s * rl:e * rl])).to(device)        # one host copy out of the page cache
-        out[s:e] = ops.las_records_xyz(rec, e - s, rl)
-    del mm
+    if n == 0:
+        return hdr, out
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        ws = ops._workspace(L.pch_las_read_ws_bytes(), torch.device(device))
+        _lib.check(L.pch_las_read_xyz_i32(os.fsencode(path), 0, n, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          torch.cuda.current_stream().cuda_stream))
     return hdr, out
+
+
+def write_device(path, header, XYZ_dev):
+    """Writes int32 [n,3] X,Y,Z that live on the device (pch_las_write_xyz_i32): header's point_format /
+    version / scales / offsets, every other record field zero.  Returns the header written."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    XYZ_dev = XYZ_dev.contiguous()
+    if not XYZ_dev.is_cuda or XYZ_dev.dtype != torch.int32:
+        raise TypeError("XYZ must be an int32 CUDA/HIP tensor")
+    d = os.path.dirname(os.path.abspath(path))
+    os.makedirs(d, exist_ok=True)
+    h = _lib.LasHeaderC()
+    h.version_major, h.version_minor = int(header.version[0]), int(header.version[1])
+    h.point_format = int(header.point_format)
+    for a in range(3):
+        h.scales[a] = float(header.scales[a])
+        h.offsets[a] = float(header.offsets[a])
+    n = int(XYZ_dev.shape[0])
+    with torch.cuda.device(XYZ_dev.device):
+        _lib.check(_lib.lib().pch_las_write_xyz_i32(os.fsencode(path), C.addressof(h), XYZ_dev.data_ptr(), n,
+                                                    torch.cuda.current_stream().cuda_stream))
+    return read_header_native(path)
 
 
 def write(path, header, XYZ):

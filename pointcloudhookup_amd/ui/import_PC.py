@@ -61,11 +61,11 @@ def run_voxel_downsampling(
         del XYZ
         _, mean, _, offs = ops.voxel_downsample(xyz, float(voxel_size), int(chunk_size))
         del xyz
-        out_XYZ = ops.las_unscale(mean, hdr.scales, hdr.offsets).cpu().numpy()   # :61-63
+        out_XYZ = ops.las_unscale(mean, hdr.scales, hdr.offsets)                 # :61-63
         n_out = int(mean.shape[0])
         del mean
     else:
-        out_XYZ = np.zeros((0, 3), np.int32)
+        out_XYZ = torch.zeros((0, 3), dtype=torch.int32, device=dev)
         n_out = 0
 
     # the reference reports per chunk while it loops (:45-58); here all chunks are done
@@ -76,8 +76,8 @@ def run_voxel_downsampling(
         if progress_callback:
             progress_callback(int((end / total_points) * 100))
 
-    _las.write(output_path, _las.LasHeader(point_format=hdr.point_format, version=hdr.version,
-                                           scales=hdr.scales, offsets=hdr.offsets), out_XYZ)
+    _las.write_device(output_path, _las.LasHeader(point_format=hdr.point_format, version=hdr.version,
+                                                  scales=hdr.scales, offsets=hdr.offsets), out_XYZ)
     ops.release_workspace()
 
     if log_callback:

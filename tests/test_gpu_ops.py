@@ -448,3 +448,54 @@ def test_count_at_offset_is_an_integer_above_2_pow_24(cuda):
     assert gf["count"] == (1 << 24) + 1 and gf["count_at_offset"] == (1 << 24) + 1
     g2 = ops.tower_clusters(raw, pct=0.01, segment=False)[0]
     assert g2["count_at_offset"] == (1 << 24) + 1
+
+
+# ------------------------------------------------------------------------------ native LAS I/O
+def test_native_las_reader_on_byte_built_files(cuda, tmp_path):
+    """pch_las_read_xyz_i32 against files assembled from the LAS specification in tests/las_bytes.py (not by
+    our own writer): VLRs, padding in front of the point data, extra bytes, odd record lengths (misaligned
+    X/Y/Z), LAS 1.4 with the 64-bit count only, and a file larger than one 32 MiB hop of the pinned buffer."""
+    import las_bytes
+    from pointcloudhookup_amd import las
+    rng = np.random.default_rng(5)
+    cases = [dict(n=1000, point_format=3, version=(1, 2)),
+             dict(n=777, point_format=2, version=(1, 2), vlr_payloads=(b"x" * 40, b"y" * 7), pad_before_points=13),
+             dict(n=4097, point_format=1, version=(1, 3), extra_bytes=5),
+             dict(n=5000, point_format=6, version=(1, 4), vlr_payloads=(b"z" * 100,), extra_bytes=3),
+             dict(n=0, point_format=0, version=(1, 2)),
+             dict(n=1_300_000, point_format=7, version=(1, 4), extra_bytes=1)]      # 37-byte records, 2 hops
+    for i, kw in enumerate(cases):
+        n = kw.pop("n")
+        XYZ = rng.integers(-2**31, 2**31 - 1, size=(n, 3), dtype=np.int64).astype(np.int32)
+        p = str(tmp_path / f"c{i}.las")
+        las_bytes.build(p, XYZ, **kw)
+        hdr, dev = las.read_device(p, cuda)
+        assert dev.shape == (n, 3) and dev.dtype == torch.int32
+        np.testing.assert_array_equal(dev.cpu().numpy(), XYZ)
+        np.testing.assert_array_equal(las.read(p).XYZ, XYZ)          # the python reader agrees
+
+
+def test_native_las_writer_roundtrip_and_layout(cuda, tmp_path):
+    import las_bytes
+    from pointcloudhookup_amd import las
+    rng = np.random.default_rng(6)
+    for n, fmt, ver in ((0, 3, (1, 2)), (1, 0, (1, 2)), (5000, 3, (1, 2)), (3_000_000, 1, (1, 3)), (1234, 6, (1, 4))):
+        XYZ = rng.integers(-10**9, 10**9, size=(n, 3), dtype=np.int64).astype(np.int32)
+        p = str(tmp_path / f"w{n}.las")
+        hdr = las.LasHeader(point_format=fmt, version=ver, scales=np.array([0.001, 0.002, 0.01]),
+                            offsets=np.array([437000.0, 3139000.0, -5.0]))
+        back = las.write_device(p, hdr, torch.from_numpy(XYZ).to(cuda))
+        got = las_bytes.parse_xyz(p)                                  # spec-level parse of what the library wrote
+        assert got["n"] == n == back.point_count and got["point_format"] == fmt and got["version"] == ver
+        assert got["offset_to_points"] == got["header_size"] and got["num_vlrs"] == 0
+        assert got["record_length"] == las.RECORD_LEN[fmt]
+        np.testing.assert_array_equal(got["XYZ"], XYZ)
+        assert not got["other_bytes"].any()                           # every other record field is zero
+        np.testing.assert_array_equal(got["scales"], hdr.scales)
+        np.testing.assert_array_equal(got["offsets"], hdr.offsets)
+        if n:
+            np.testing.assert_array_equal(got["mins"], XYZ.min(0) * hdr.scales + hdr.offsets)
+            np.testing.assert_array_equal(got["maxs"], XYZ.max(0) * hdr.scales + hdr.offsets)
+        ref = str(tmp_path / f"r{n}.las")                             # same bytes as the python writer (drop-in files)
+        las.write(ref, hdr, XYZ)
+        assert open(ref, "rb").read() == open(p, "rb").read()

@@ -384,3 +384,38 @@ def test_cluster_tiled_equals_global_dbscan_gloo(tmp_path, oracle_clib, world):
     for its own points equal ONE DBSCAN over the whole cloud (exchange and union-find over gloo; the local
     fit is the CPU oracle here, the HIP kernels in tests/test_gpu_e2e.py)."""
     _run_tiled(tmp_path, world, "cpu", 29741 + world)
+
+
+# ------------------------------------------------------------------ native LAS header parse (no GPU needed)
+def test_native_las_header_on_byte_built_files(tmp_path):
+    import las_bytes
+    from pointcloudhookup_amd import las
+    from pointcloudhookup_amd._lib import PchError
+    rng = np.random.default_rng(3)
+    XYZ = rng.integers(-2**31, 2**31 - 1, size=(1000, 3), dtype=np.int64).astype(np.int32)
+    cases = [dict(point_format=3, version=(1, 2)),
+             dict(point_format=2, version=(1, 2), vlr_payloads=(b"x" * 40, b"y" * 7), pad_before_points=13),
+             dict(point_format=1, version=(1, 3), extra_bytes=6),
+             dict(point_format=6, version=(1, 4), vlr_payloads=(b"z" * 100,), extra_bytes=3),
+             dict(point_format=0, version=(1, 4), legacy_count_zero=True)]
+    for i, kw in enumerate(cases):
+        p = str(tmp_path / f"c{i}.las")
+        want = las_bytes.build(p, XYZ, **kw)
+        for h in (las.read_header_native(p), las.read_header(p)):       # the library and the python parser agree
+            assert h.point_count == want["n"] and h.record_length == want["record_length"]
+            assert h.offset_to_points == want["offset_to_points"] and h.header_size == want["header_size"]
+            assert h.point_format == want["point_format"] and tuple(h.version) == want["version"]
+            np.testing.assert_array_equal(h.scales, want["scales"])
+            np.testing.assert_array_equal(h.offsets, want["offsets"])
+            np.testing.assert_array_equal(h.mins, want["mins"])
+            np.testing.assert_array_equal(h.maxs, want["maxs"])
+    bad = tmp_path / "bad.las"
+    bad.write_bytes(b"NOPE" + b"\0" * 400)
+    with pytest.raises(PchError):
+        las.read_header_native(str(bad))
+    trunc = tmp_path / "trunc.las"
+    trunc.write_bytes(open(str(tmp_path / "c0.las"), "rb").read()[:5000])
+    with pytest.raises(PchError):
+        las.read_header_native(str(trunc))
+    with pytest.raises(FileNotFoundError):
+        las.read_header_native(str(tmp_path / "missing.las"))
