@@ -214,6 +214,24 @@ int pch_segment_by_label(const int32_t* labels, const float* xyz, int64_t n,
                          int32_t nclusters, int32_t* out_perm, int64_t* out_offsets,
                          float* out_stats, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------ viewer helpers
+ * Axis-aligned crop, bounds INCLUSIVE, order preserving:
+ *   points[(x>=x0)&(x<=x1)&(y>=y0)&(y<=y1)&(z>=z0)&(z<=z1)]
+ * Replaces: the per-tower mask + gather of test/kuangxuan.py:69-79 (the box a tower's kuangxuan wire frame shows).
+ * xyz [n,3] float64; out_points [n,3] float64 capacity; out_index [n] int64 (may be NULL): source rows;
+ * out_count [1] int64.  Rows holding NaN fail the comparisons and are dropped, as in numpy. */
+size_t pch_crop_aabb_ws_bytes(int64_t n);
+int pch_crop_aabb_f64(const double* xyz, int64_t n, const double* min3_host, const double* max3_host,
+                      double* out_points, int64_t* out_index, int64_t* out_count,
+                      void* ws, size_t ws_bytes, void* stream);
+/* Preview decimation: k distinct rows chosen by a seeded pseudo-random bijection of the row range.
+ * Replaces: points[np.random.choice(len(points), k, replace=False)] (pyGUI_towers_test.py:174-177 with k =
+ * 200 000, ui/vtk_widget.py:115-118 with k = 500 000).  numpy's draw is unseeded there, so parity is a
+ * property: exactly k rows, no row twice, every row from the input, order arbitrary.
+ * out_points [k,3] float64 (may be NULL), out_index [k] int64 (may be NULL). */
+int pch_decimate_f64(const double* xyz, int64_t n, int64_t k, uint64_t seed,
+                     double* out_points, int64_t* out_index, void* stream);
+
 /* ------------------------------------------------------- stages B + C + D0 in one call
  * The body of extract_towers between "points are loaded" and the per-label loop
  * (utils/tower_extraction.py:62-125): pch_ground_filter_f32, pch_dbscan_f32 on the kept points

@@ -1,0 +1,159 @@
+// Viewer-side helpers the reference runs on the host over the whole cloud at every redraw
+// (SURVEY.md section 8f-3): the axis-aligned crop of a tower's box and the random preview decimation.
+//   crop     : points[(x>=x0)&(x<=x1)&(y>=y0)&(y<=y1)&(z>=z0)&(z<=z1)]     test/kuangxuan.py:69-79
+//   decimate : points[np.random.choice(len(points), k, replace=False)]      pyGUI_towers_test.py:174-177,
+//                                                                           ui/vtk_widget.py:115-118
+#include "pch_common.h"
+#include "pch_lookback.h"
+
+namespace pch {
+
+constexpr int CR_THREADS = 256;
+constexpr int CR_ROUNDS  = 8;
+constexpr int CR_TILE    = CR_THREADS * CR_ROUNDS;          // 2048 rows per workgroup
+
+struct CropBox { double lo[3], hi[3]; };
+struct Row64 { double x, y, z; };
+
+struct CropState { uint32_t ticket, total, pad[2]; };
+
+// order-preserving compaction in one sweep: tiles are taken by ticket (order of arrival), the output
+// offset of a tile comes from a decoupled look-back over the tiles in front of it
+__global__ __launch_bounds__(CR_THREADS) void crop_aabb_k(const double* __restrict__ xyz, int64_t n, CropBox box,
+                                                          CropState* __restrict__ st, uint64_t* __restrict__ status,
+                                                          double* __restrict__ out_points,
+                                                          int64_t* __restrict__ out_index,
+                                                          int64_t* __restrict__ out_count) {
+    __shared__ uint32_t wtot[CR_THREADS / 64];
+    __shared__ uint32_t tile_sh, excl_sh;
+    if (threadIdx.x == 0) tile_sh = atomicAdd(&st->ticket, 1u);
+    __syncthreads();
+    const int64_t tile = tile_sh;
+    const int w = wave_id(), l = lane_id();
+    const int64_t seg = tile * CR_TILE + (int64_t)w * (64 * CR_ROUNDS);
+    const Row64* __restrict__ rows = reinterpret_cast<const Row64*>(xyz);
+    Row64 q[CR_ROUNDS];
+    unsigned long long m[CR_ROUNDS];
+    uint32_t run = 0;
+#pragma unroll
+    for (int r = 0; r < CR_ROUNDS; ++r) {
+        const int64_t i = seg + r * 64 + l;
+        q[r] = rows[i < n ? i : 0];
+    }
+#pragma unroll
+    for (int r = 0; r < CR_ROUNDS; ++r) {
+        const int64_t i = seg + r * 64 + l;
+        const bool keep = i < n && q[r].x >= box.lo[0] && q[r].x <= box.hi[0] && q[r].y >= box.lo[1] &&
+                          q[r].y <= box.hi[1] && q[r].z >= box.lo[2] && q[r].z <= box.hi[2];
+        m[r] = __ballot(keep);
+        run += (uint32_t)__popcll(m[r]);
+    }
+    if (l == 0) wtot[w] = run;
+    __syncthreads();
+    const uint32_t T = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    if (w == 0) {
+        const uint32_t e = gf_lookback(status, tile, T);
+        if (l == 0) {
+            excl_sh = e;
+            if (tile == (int64_t)gridDim.x - 1) *out_count = (int64_t)e + T;
+        }
+    }
+    __syncthreads();
+    if (T == 0) return;
+    uint32_t woff = excl_sh;
+    for (int w2 = 0; w2 < w; ++w2) woff += wtot[w2];
+    const uint64_t lt = lanemask_lt();
+#pragma unroll
+    for (int r = 0; r < CR_ROUNDS; ++r) {
+        if ((m[r] >> l) & 1ull) {
+            const int64_t o = (int64_t)woff + (uint32_t)__popcll(m[r] & lt);
+            reinterpret_cast<Row64*>(out_points)[o] = q[r];
+            if (out_index) out_index[o] = seg + r * 64 + l;
+        }
+        woff += (uint32_t)__popcll(m[r]);
+    }
+}
+
+// ---- seeded sampling without replacement: a keyed bijection of [0, 2^b) (four Feistel rounds) walked
+// until it lands inside [0, n) maps 0..k-1 to k distinct rows
+__device__ __forceinline__ uint32_t dc_round(uint32_t x, uint32_t key) {
+    x ^= key;
+    x *= 0x9E3779B1u;
+    x ^= x >> 15;
+    x *= 0x85EBCA77u;
+    x ^= x >> 13;
+    return x;
+}
+__device__ __forceinline__ uint64_t dc_permute(uint64_t v, int half_bits, const uint32_t (&keys)[4]) {
+    const uint32_t mask = half_bits >= 32 ? 0xFFFFFFFFu : ((1u << half_bits) - 1u);
+    uint32_t L = (uint32_t)(v >> half_bits) & mask, R = (uint32_t)v & mask;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t t = L ^ (dc_round(R, keys[r]) & mask);
+        L = R;
+        R = t;
+    }
+    return ((uint64_t)L << half_bits) | R;
+}
+__global__ void decimate_k(const double* __restrict__ xyz, int64_t n, int64_t k, int half_bits, uint64_t seed,
+                           double* __restrict__ out_points, int64_t* __restrict__ out_index) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    const uint32_t keys[4] = {(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)seed * 0x632BE5ABu + 0x9E3779B9u,
+                              (uint32_t)(seed >> 32) * 0x85EBCA6Bu + 0xC2B2AE35u};
+    uint64_t v = (uint64_t)j;
+    do { v = dc_permute(v, half_bits, keys); } while (v >= (uint64_t)n);     // cycle walking: expected < 4 steps
+    if (out_index) out_index[j] = (int64_t)v;
+    if (out_points) reinterpret_cast<Row64*>(out_points)[j] = reinterpret_cast<const Row64*>(xyz)[v];
+}
+
+}  // namespace pch
+
+using namespace pch;
+
+extern "C" size_t pch_crop_aabb_ws_bytes(int64_t n) {
+    if (n < 0) return 0;
+    Arena a;
+    a.take<CropState>(1);
+    a.take<uint64_t>(ceil_div(n > 0 ? n : 1, CR_TILE));
+    return a.off;
+}
+
+extern "C" int pch_crop_aabb_f64(const double* xyz, int64_t n, const double* min3_host, const double* max3_host,
+                                 double* out_points, int64_t* out_index, int64_t* out_count, void* ws,
+                                 size_t ws_bytes, void* stream) {
+    PCH_DEVICE_GUARD(out_count);
+    hipStream_t s = (hipStream_t)stream;
+    PCH_REQUIRE(n >= 0 && n < (int64_t(1) << 32) && min3_host && max3_host && out_count, "bad argument");
+    if (n == 0) {
+        PCH_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(int64_t), s));
+        return PCH_OK;
+    }
+    PCH_REQUIRE(xyz && out_points && ws, "null buffer");
+    Arena a(ws, ws_bytes);
+    CropState* st = a.take<CropState>(1);
+    const int64_t nt = ceil_div(n, CR_TILE);
+    uint64_t* status = a.take<uint64_t>(nt);
+    if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
+    PCH_HIP_TRY(hipMemsetAsync(ws, 0, a.off, s));
+    CropBox box;
+    for (int k = 0; k < 3; ++k) { box.lo[k] = min3_host[k]; box.hi[k] = max3_host[k]; }
+    PCH_LAUNCH("crop_aabb", crop_aabb_k, dim3((unsigned)nt), dim3(CR_THREADS), 0, s, xyz, n, box, st, status,
+               out_points, out_index, out_count);
+    return PCH_OK;
+}
+
+extern "C" int pch_decimate_f64(const double* xyz, int64_t n, int64_t k, uint64_t seed, double* out_points,
+                                int64_t* out_index, void* stream) {
+    PCH_DEVICE_GUARD(out_points ? (const void*)out_points : (const void*)out_index);
+    PCH_REQUIRE(n >= 0 && k >= 0 && k <= n, "Cannot take a larger sample than population when 'replace=False'");
+    if (k == 0) return PCH_OK;
+    PCH_REQUIRE(out_points || out_index, "no output buffer");
+    PCH_REQUIRE(!out_points || xyz, "null input");
+    int bits = bits_for((uint64_t)n);
+    if (bits < 2) bits = 2;
+    const int half_bits = (bits + 1) / 2;
+    PCH_LAUNCH("decimate", decimate_k, dim3((unsigned)ceil_div(k, 256)), dim3(256), 0, (hipStream_t)stream, xyz, n, k,
+               half_bits, (uint64_t)seed, out_points, out_index);
+    return PCH_OK;
+}

@@ -337,3 +337,40 @@ def segment_by_label(labels, xyz, nclusters):
         _lib.check(L.pch_segment_by_label(_ptr(labels), _ptr(xyz), n, K, _ptr(perm), _ptr(offsets),
                                           _ptr(stats), _ptr(ws), ws.numel(), _stream()))
     return perm, offsets, stats[:K]
+
+
+# ---------------------------------------------------------------------------- viewer helpers
+def crop_aabb(xyz, lo, hi, want_index=False):
+    """points[(p >= lo).all(1) & (p <= hi).all(1)] for float64 [n,3], order preserving (test/kuangxuan.py:69-79).
+    Returns points [m,3] (and source rows int64 [m]).  Synchronises (reads m)."""
+    import ctypes as C
+    L = _lib.lib()
+    xyz = _need_cuda(xyz, torch.float64, "xyz").reshape(-1, 3)
+    n = xyz.shape[0]
+    dev = xyz.device
+    mn = (C.c_double * 3)(*[float(v) for v in lo])
+    mx = (C.c_double * 3)(*[float(v) for v in hi])
+    with torch.cuda.device(dev):
+        out = torch.empty((n, 3), dtype=torch.float64, device=dev)
+        idx = torch.empty((n,), dtype=torch.int64, device=dev) if want_index else None
+        cnt = torch.zeros((1,), dtype=torch.int64, device=dev)
+        ws = _workspace(L.pch_crop_aabb_ws_bytes(n), dev)
+        _lib.check(L.pch_crop_aabb_f64(_ptr(xyz), n, C.cast(mn, C.c_void_p), C.cast(mx, C.c_void_p), _ptr(out),
+                                       _ptr(idx), _ptr(cnt), _ptr(ws), ws.numel(), _stream()))
+        m = int(cnt.item())
+    return (out[:m], idx[:m]) if want_index else out[:m]
+
+
+def decimate(xyz, k, seed=0, want_index=False):
+    """k distinct rows of float64 [n,3] (seeded; pyGUI_towers_test.py:174-177, ui/vtk_widget.py:115-118)."""
+    L = _lib.lib()
+    xyz = _need_cuda(xyz, torch.float64, "xyz").reshape(-1, 3)
+    n, k = xyz.shape[0], int(k)
+    if k > n:
+        raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+    dev = xyz.device
+    with torch.cuda.device(dev):
+        out = torch.empty((k, 3), dtype=torch.float64, device=dev)
+        idx = torch.empty((k,), dtype=torch.int64, device=dev) if want_index else None
+        _lib.check(L.pch_decimate_f64(_ptr(xyz), n, k, int(seed) & (2**64 - 1), _ptr(out), _ptr(idx), _stream()))
+    return (out, idx) if want_index else out

@@ -424,8 +424,80 @@ def reference_runs(which=None):
               "towers", len(u["towers"]), "/", len(s["towers"]), "logs", len(u["logs"]))
 
 
+def gim_match_contract():
+    """Runs the reference's OWN consumer of the tower dicts (utils/table_match_gim.py::match_towers) on the
+    towers of refrun_config1_1m / refrun_towers5x3 and writes tests/golden/gim_match.json.  PyQt5 and pyproj
+    are not installed: empty placeholder modules stand in (the module only needs their names at import time;
+    its geoid transformer then runs in its documented fallback mode, ellipsoid height - 25 m)."""
+    import contextlib
+    import importlib
+    import io
+    if not os.path.isdir(REF):
+        raise SystemExit("reference tree not present")
+
+    class _Any:
+        def __init__(self, *a, **k): pass
+        def __getattr__(self, n): return _Any()
+        def __call__(self, *a, **k): return _Any()
+
+    def fake(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        m.__getattr__ = lambda n: _Any
+        return m
+
+    def no_grid(*a, **k):
+        raise RuntimeError("no geoid grid offline")
+
+    stubs = {"PyQt5": fake("PyQt5"), "PyQt5.QtWidgets": fake("PyQt5.QtWidgets"), "PyQt5.QtCore": fake("PyQt5.QtCore"),
+             "PyQt5.QtGui": fake("PyQt5.QtGui"),
+             "pyproj": fake("pyproj", Transformer=types.SimpleNamespace(from_pipeline=no_grid),
+                            datadir=types.SimpleNamespace(get_data_dir=lambda: "/nonexistent"))}
+    saved = {k: sys.modules.get(k) for k in stubs}
+    sys.modules.update(stubs)
+    sys.path.insert(0, REF)
+    out = {"note": "output of the reference's utils/table_match_gim.py::match_towers (fallback geoid mode) on the "
+                   "towers of the refrun fixtures; transformer: lon = 112 + (x - 437000) * 1e-5, lat = 28 + (y - 3139000) * 9e-6",
+           "cases": {}}
+    try:
+        tm = importlib.import_module("utils.table_match_gim")
+
+        class T:
+            def transform(self, x, y):
+                return 112.0 + (x - 437000.0) * 1e-5, 28.0 + (y - 3139000.0) * 9e-6
+
+        for case in ("config1_1m", "towers5x3"):
+            g = np.load(os.path.join(HERE, f"refrun_{case}.npz"))
+            towers = [dict(center=g["trimesh_sorted_center"][i], height=float(g["trimesh_sorted_height"][i]),
+                           north_angle=float(g["trimesh_sorted_north_angle"][i]))
+                      for i in range(len(g["trimesh_sorted_center"]))]
+            tr = T()
+            gim = []
+            for k, t in enumerate(towers):                  # GIM towers: near the 1st, 60 m off the 2nd, 150 m too high for the 3rd ...
+                lon, lat = tr.transform(t["center"][0], t["center"][1])
+                dx = [5.0, 60.0, 10.0, 0.0, 49.0][k % 5]
+                dh = [0.0, 0.0, 150.0, -99.0, 3.0][k % 5]
+                gim.append({"lat": lat, "lng": lon + dx / 97000.0, "h": t["center"][2] - 25.0 + dh})
+            with contextlib.redirect_stdout(io.StringIO()):
+                matched, conv = tm.match_towers(gim, towers, tr)
+            out["cases"][case] = {"gim": gim, "matched": [list(m) for m in matched],
+                                  "converted": [{k: (list(map(float, v)) if hasattr(v, "__len__") and not isinstance(v, str) else v)
+                                                 for k, v in c.items()} for c in conv]}
+            print(case, "towers", len(towers), "matched", matched)
+    finally:
+        sys.path.remove(REF)
+        for k in [m for m in sys.modules if m == "utils" or m.startswith("utils.")]:
+            del sys.modules[k]
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    json.dump(out, open(os.path.join(HERE, "gim_match.json"), "w"), indent=1, default=float)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dbscan", "numpy", "boxes", "e2e", "refrun"]
+    which = sys.argv[1:] or ["dbscan", "numpy", "boxes", "e2e", "refrun", "gim"]
     if "dbscan" in which:
         dbscan_cases()
     if "numpy" in which:
@@ -434,5 +506,7 @@ if __name__ == "__main__":
         kuangxuan_boxes()
     if "e2e" in which:
         e2e_config1()
+    if "gim" in which:
+        gim_match_contract()
     if any(w == "refrun" or w.startswith("refrun:") for w in which):
         reference_runs([w.split(":", 1)[1] for w in which if w.startswith("refrun:")] or None)

@@ -99,6 +99,17 @@ def test_dropin_extract_towers_on_reference_run(cuda, case, order, tmp_path, mon
         np.testing.assert_array_equal(t["rotation"], g[f"{order}_rotation"][i])
         assert t["north_angle"] == g[f"{order}_north_angle"][i]
         assert _sha(t["points"]) == str(g[f"{order}_points_sha"][i])
+    if order == "trimesh_sorted" and case in ("config1_1m", "towers5x3"):
+        # the consumer of these dicts (utils/table_match_gim.py reads center / height / north_angle): same matches
+        # as the reference's own match_towers made of the reference-run towers (tests/golden/gim_match.json)
+        from oracle import gim_match as ogm
+        gold = json.load(open(os.path.join(GOLD, "gim_match.json")))["cases"][case]
+        matched, conv = ogm.match_towers(gold["gim"], towers,
+                                         lambda x, y: (112.0 + (x - 437000.0) * 1e-5, 28.0 + (y - 3139000.0) * 9e-6))
+        assert [list(m) for m in matched] == gold["matched"]
+        for c, w in zip(conv, gold["converted"]):
+            np.testing.assert_array_equal(np.array(c["converted_center"]), np.array(w["converted_center"]))
+            assert c["height"] == w["height"] and c["north_angle"] == w["north_angle"]
     if order == "unsorted":
         for name, want in zip(g["las_paths"], g["las_XYZ_sha"]):
             got = las.read(str(tmp_path / "output_towers" / str(name)))

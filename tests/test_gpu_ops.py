@@ -499,3 +499,52 @@ def test_native_las_writer_roundtrip_and_layout(cuda, tmp_path):
         ref = str(tmp_path / f"r{n}.las")                             # same bytes as the python writer (drop-in files)
         las.write(ref, hdr, XYZ)
         assert open(ref, "rb").read() == open(p, "rb").read()
+
+
+# ------------------------------------------------------------------------------ viewer helpers
+@pytest.mark.parametrize("n", [0, 1, 63, 4095, 4096, 4097, 70001, 1_000_003])
+def test_crop_aabb_equals_numpy_mask(cuda, n):
+    """test/kuangxuan.py:69-79: inclusive bounds, order preserved, NaN rows dropped."""
+    rng = np.random.default_rng(n + 1)
+    pts = rng.random((n, 3)) * [400.0, 100.0, 60.0] + OFFSET
+    pts[: n // 4] = np.round(pts[: n // 4], 0)                  # many rows exactly ON a bound
+    if n > 10:
+        pts[5, 1] = np.nan
+    c = OFFSET + [200.0, 50.0, 20.0]
+    w, h = 40.0, 15.0
+    lo = np.array([np.round(c[0] - w / 1), c[1] - w / 2, c[2] - h / 1])       # the reference's own box arithmetic
+    hi = np.array([np.round(c[0] + w / 0.6), c[1] + w / 1, c[2] + h * 2])
+    mask = ((pts[:, 0] >= lo[0]) & (pts[:, 0] <= hi[0]) & (pts[:, 1] >= lo[1]) & (pts[:, 1] <= hi[1])
+            & (pts[:, 2] >= lo[2]) & (pts[:, 2] <= hi[2]))
+    got, idx = ops.crop_aabb(_dev(pts, cuda), lo, hi, want_index=True)
+    np.testing.assert_array_equal(got.cpu().numpy(), pts[mask])
+    np.testing.assert_array_equal(idx.cpu().numpy(), np.flatnonzero(mask))
+    if n:
+        everything = ops.crop_aabb(_dev(pts, cuda), [-np.inf] * 3, [np.inf] * 3)
+        assert everything.shape[0] == n - (1 if n > 10 else 0)
+        assert ops.crop_aabb(_dev(pts, cuda), [1e9] * 3, [2e9] * 3).shape[0] == 0
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (10, 10), (1000, 7), (200001, 200000), (3_000_000, 500000), (5, 0)])
+def test_decimate_is_a_sample_without_replacement(cuda, n, k):
+    """np.random.choice(n, k, replace=False) is unseeded in the reference: parity is the property - exactly k rows,
+    none twice, all from the input; the same seed gives the same rows, another seed other rows."""
+    rng = np.random.default_rng(n)
+    pts = rng.random((n, 3)) + OFFSET
+    dev = _dev(pts, cuda)
+    out, idx = ops.decimate(dev, k, seed=12345, want_index=True)
+    idx_h = idx.cpu().numpy()
+    assert out.shape == (k, 3) and len(np.unique(idx_h)) == k
+    if k:
+        assert idx_h.min() >= 0 and idx_h.max() < n
+    np.testing.assert_array_equal(out.cpu().numpy(), pts[idx_h])
+    again = ops.decimate(dev, k, seed=12345, want_index=True)[1].cpu().numpy()
+    np.testing.assert_array_equal(again, idx_h)
+    if 0 < k < n and n > 100:
+        other = ops.decimate(dev, k, seed=999, want_index=True)[1].cpu().numpy()
+        assert not np.array_equal(np.sort(other), np.sort(idx_h))
+    if k >= 1000 and k < n:                                      # roughly uniform: every tenth of the rows gets its share
+        share = np.bincount((idx_h * 10 // n).astype(np.int64), minlength=10) / k
+        assert share.min() > 0.05 and share.max() < 0.2
+    with pytest.raises(ValueError):
+        ops.decimate(dev, n + 1)

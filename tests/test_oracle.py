@@ -296,3 +296,28 @@ def test_oracle_reproduces_reference_run(oracle_clib, case):
         orig = (t["points"] + gf["centroid"]).astype(np.float64)
         XYZ_out = np.stack([ovx.las_unscale(orig[:, a], sc[a], of[a]) for a in range(3)], axis=1)
         assert _sha(XYZ_out) == str(want)
+
+
+# ------------------------------------------------------------------ consumer contract
+def _gim_transform(x, y):
+    return 112.0 + (x - 437000.0) * 1e-5, 28.0 + (y - 3139000.0) * 9e-6
+
+
+@pytest.mark.parametrize("case", ["config1_1m", "towers5x3"])
+def test_gim_matching_consumer_contract(case):
+    """utils/table_match_gim.py reads tower['center'] (x, y, z), ['height'] and ['north_angle'] of the dicts
+    extract_towers returns.  tests/golden/gim_match.json holds what the reference's own match_towers made of the
+    reference-run towers; the restatement in oracle/gim_match.py must reproduce it from the same dict fields."""
+    from oracle import gim_match as ogm
+    gold = json.load(open(os.path.join(GOLD, "gim_match.json")))["cases"][case]
+    g = np.load(os.path.join(GOLD, f"refrun_{case}.npz"))
+    towers = [dict(center=g["trimesh_sorted_center"][i], height=float(g["trimesh_sorted_height"][i]),
+                   north_angle=float(g["trimesh_sorted_north_angle"][i])) for i in range(len(g["trimesh_sorted_center"]))]
+    matched, conv = ogm.match_towers(gold["gim"], towers, _gim_transform)
+    assert [list(m) for m in matched] == gold["matched"]
+    for c, w in zip(conv, gold["converted"]):
+        assert c["id"] == w["id"] and c["height"] == w["height"] and c["north_angle"] == w["north_angle"]
+        np.testing.assert_array_equal(np.array(c["converted_center"]), np.array(w["converted_center"]))
+        assert c["n_value"] == w["n_value"] == 25.0
+    for t in towers:                                       # what the consumer relies on
+        assert len(t["center"]) == 3 and 0.0 <= t["north_angle"] < 360.0 and t["height"] > 0.0
