@@ -3,10 +3,11 @@ ground-removal + tower-clustering hot path behind the reference's own call surfa
 
   csrc/                hand-written HIP kernels + the C ABI (include/pch_hip.h) -> libpch_hip.so
   _lib.py, ops.py      ctypes binding and tensor-level operators (no CPU fallback)
-  pipeline.py          host orchestration of stages B-D on device tensors
-  towers.py, obb.py    per-cluster boxes, tower acceptance, de-dup (host side of stage D)
-  las.py               minimal LAS 1.x reader/writer (laspy is not a dependency)
-  tiles.py             one-process-per-GPU tile sharding + RCCL label reconciliation
+  pipeline.py          host orchestration of stages B-D0 on device tensors, tower acceptance / de-dup (D2-D3)
+  obb.py               per-cluster oriented boxes on the host (stage D1, scipy qhull, worker processes)
+  las.py               LAS 1.x I/O: python header parser / host writer + the library's native reader / writer
+  tiles.py             one process per GPU: tile streams, x-tiles with halo, label reconciliation (RCCL / gloo)
+  synth.py             the seeded synthetic clouds of SURVEY.md section 8d
   ui/, utils/          drop-in modules with the reference's names and signatures
 """
 __version__ = "0.1.0"

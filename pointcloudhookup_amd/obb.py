@@ -4,9 +4,11 @@
 trimesh is not a dependency; this module implements the same published procedure on
 scipy's qhull binding (the library trimesh itself calls): 3-D hull -> candidate normals
 (hemisphere folded, de-duplicated at 0.1 rad in spherical coordinates) -> per candidate a
-minimum-area rectangle of the projected hull -> smallest volume wins.  The hull only ever
-sees a few thousand points: clusters are pre-reduced on the GPU (pipeline.py) and the
-hull vertices, not the cluster points, drive the candidate loop.
+minimum-area rectangle of the projected hull -> smallest volume wins.  qhull sees the FULL
+cluster, like trimesh's: a hull pre-filter changes which near-coplanar facets qhull merges and
+moved a box centre by 1.3 cm in 1 of 12 trials, more than the 1e-3 m the
+north star allows.  Cost per 43 000-point cluster: ~10 ms for the 3-D hull, ~18 ms for the ~80
+candidate directions (one 2-D qhull call each over the ~60 hull vertices).
 
 ``extent_order='unsorted'`` (default) returns extents as [rect_long, rect_short,
 normal_extent] - the behaviour the authors' recorded run shows
@@ -179,11 +181,14 @@ def _workers(n):
 
 def boxes_of(clusters, extent_order="unsorted", workers=None):
     """Yields ((extents, transform), None) or (None, exception) for every (n_k,3) array in
-    ``clusters``, in order.  workers: None -> PCH_OBB_WORKERS (default 1 = in this process)."""
+    ``clusters``, in order.  workers: None -> PCH_OBB_WORKERS; unset: up to 8 worker processes once there are
+    at least 16 clusters (a 100 M-point tile has hundreds, ~25 ms of qhull each), none for small jobs.
+    The boxes are identical either way."""
     import os
-    if workers is None:
-        workers = int(os.environ.get("PCH_OBB_WORKERS", "1") or "1")
     clusters = list(clusters)
+    if workers is None:
+        env = os.environ.get("PCH_OBB_WORKERS")
+        workers = int(env) if env else (min(8, os.cpu_count() or 1) if len(clusters) >= 16 else 1)
     if workers <= 1 or len(clusters) < 2:
         for c in clusters:
             yield _boxed((c, extent_order))
