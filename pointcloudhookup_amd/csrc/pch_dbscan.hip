@@ -186,6 +186,75 @@ __global__ __launch_bounds__(DB_THREADS) void db_keys_k(const float* __restrict_
     keys[i] = db_pack(g, (uint64_t)(i / g.chunk_size), cz, cy, cx);
 }
 
+// ---- fallback for grids that do not fit the 64-bit key (extent/eps astronomically large: outliers, heavy
+// tails): per-axis COMPRESSED cell coordinates.  The points are sorted along the axis; a gap of >= 3 cells
+// between consecutive points starts a new segment (nothing on one side of such a gap is within eps of
+// anything on the other side), cell indices are taken relative to the segment's first point (small, so the
+// float64 product is as exact as on the main path) and segments are laid out 3 units apart.  Equal
+// compressed index <=> same segment and same local cell; indices that differ by <= 2 are exactly as far
+// apart as the true ones; everything else stays >= 3 apart: the 5x5x5 neighbourhood logic is unchanged,
+// with at most 3n index values per axis.
+__global__ __launch_bounds__(DB_THREADS) void dbc_axis_keys_k(const float* __restrict__ xyz, int64_t n, int axis,
+                                                              uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = f32_ordered(xyz[3 * i + axis]);
+    vals[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(DB_THREADS) void dbc_heads_k(const uint64_t* __restrict__ keys, int64_t n, double inv_cell,
+                                                          uint32_t* __restrict__ head) {
+    const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    bool h = i == 0;
+    if (i > 0) {
+        const double a = (double)f32_unordered((uint32_t)keys[i - 1]), b = (double)f32_unordered((uint32_t)keys[i]);
+        h = (b - a) * inv_cell >= 3.0;
+    }
+    head[i] = h ? 1u : 0u;
+}
+__global__ __launch_bounds__(DB_THREADS) void dbc_local_k(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ flag,
+                                                          const uint32_t* __restrict__ excl, int64_t n, double inv_cell,
+                                                          float* __restrict__ headx, int phase,
+                                                          uint32_t* __restrict__ li, uint32_t* __restrict__ seglen,
+                                                          uint32_t* __restrict__ status) {
+    const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t seg = excl[i] + flag[i] - 1u;                     // flags are kept beside their scan
+    const float x = f32_unordered((uint32_t)keys[i]);
+    if (phase == 0) {
+        if (flag[i]) headx[seg] = x;
+        return;
+    }
+    const double v = floor(((double)x - (double)headx[seg]) * inv_cell);
+    uint32_t u = 0;
+    if (v >= 0.0 && v < 2147483000.0) u = (uint32_t)v; else atomicOr(status, 2u);
+    li[i] = u;
+    const bool last = i + 1 == n || flag[i + 1] != 0u;
+    if (last) seglen[seg] = u + 3u;                                  // next segment starts 3 units behind this one's last cell
+}
+__global__ __launch_bounds__(DB_THREADS) void dbc_comp_k(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ flag,
+                                                         const uint32_t* __restrict__ excl, const uint32_t* __restrict__ li,
+                                                         const uint32_t* __restrict__ segoff, int64_t n, int axis,
+                                                         uint32_t* __restrict__ comp, uint32_t* __restrict__ cmax) {
+    const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t seg = excl[i] + flag[i] - 1u;
+    const uint32_t c = segoff[seg] + li[i];
+    comp[3 * (int64_t)vals[i] + axis] = c;
+    if (i == n - 1) cmax[axis] = c;                                  // sorted: the last one is the largest
+}
+__global__ __launch_bounds__(DB_THREADS) void db_keys_comp_k(const uint32_t* __restrict__ comp, int64_t n, DbGrid g,
+                                                             uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    vals[i] = (uint32_t)i;
+    keys[i] = db_pack(g, 0, comp[3 * i + 2], comp[3 * i + 1], comp[3 * i + 0]);
+}
+__global__ __launch_bounds__(DB_THREADS) void db_add_offset_k(int32_t* __restrict__ labels, int64_t n, int32_t off) {
+    const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i < n && labels[i] >= 0) labels[i] += off;
+}
+
 // sorted order: gather coordinates (+ original row in .w) and flag cell heads
 __global__ __launch_bounds__(DB_THREADS) void db_gather_k(const float* __restrict__ xyz,
                                                           const uint64_t* __restrict__ keys,
@@ -1241,6 +1310,8 @@ struct DbWs {
     int64_t   rowtab_cells;
     uint32_t* chunk_bad;
     uint32_t* chunk_cells;
+    uint32_t* comp;          // [n][3] compressed cell coordinates (fallback for grids beyond the 64-bit key)
+    uint32_t* flag2;         // [n + 8] head flags kept beside their scan
 };
 
 static void db_plan(Arena& a, int64_t n, DbWs& w) {
@@ -1274,6 +1345,8 @@ static void db_plan(Arena& a, int64_t n, DbWs& w) {
     // searched on the fly
     w.rowtab_cells = nn / 4 > 65536 ? nn / 4 : (nn < 65536 ? nn : 65536);
     w.rowtab = a.take<int2>((size_t)w.rowtab_cells * DB_ROWS);
+    w.comp = a.take<uint32_t>(3 * nn);
+    w.flag2 = a.take<uint32_t>(nn + 8);
 }
 
 // PCH_DBSCAN_SORT (chunk | global), read once per process unless pch_dbscan_set_sort_mode() overrides it:
@@ -1389,24 +1462,91 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
     g.chunk_cells = w.chunk_cells;
     g.min_samples = min_samples;
     double ext[3];
-    int mc[3];
+    int mc[3] = {0, 0, 0};
+    bool overflow = false;
     for (int k = 0; k < 3; ++k) {
         ext[k] = ((double)box[3 + k] - (double)box[k]) * g.inv_cell;
-        if (!(ext[k] < 2.0e9)) { set_error("cell grid too large (extent/eps too big)"); return PCH_ERR_RANGE; }
-        mc[k] = (int)ext[k] + 1;                 // +1: slack for the rounding of the division
+        if (!(ext[k] < 2.0e9)) overflow = true;
+        else mc[k] = (int)ext[k] + 1;            // +1: slack for the rounding of the division
     }
     g.mx = mc[0]; g.my = mc[1]; g.mz = mc[2];
     g.bx = bits_for((uint64_t)g.mx + 1);
     g.by = bits_for((uint64_t)g.my + 1);
     g.bz = bits_for((uint64_t)g.mz + 1);
-    const int cellbits = g.bx + g.by + g.bz;
-    const int nbits = cellbits + bits_for((uint64_t)nchunks);
-    if (nbits > 64) {
-        set_error("cell key needs %d bits (> 64): extent/eps too large for this chunking", nbits);
-        return PCH_ERR_RANGE;
+    int cellbits = g.bx + g.by + g.bz;
+    int nbits = cellbits + bits_for((uint64_t)nchunks);
+    if (nbits > 64) overflow = true;
+    const unsigned gn = (unsigned)ceil_div(n, DB_THREADS);
+    bool compressed = false;
+    if (overflow) {
+        // extent/eps beyond the 64-bit cell key (outliers, heavy tails).  Several chunks: every chunk on its own,
+        // with its own bounding box (the reference fits them one by one anyway).  One chunk: compressed coordinates.
+        if (nchunks > 1) {
+            int32_t offset = 0;
+            for (int64_t c = 0; c < nchunks; ++c) {
+                const int64_t lo = c * chunk_size, cn = (n - lo) < chunk_size ? (n - lo) : chunk_size;
+                int32_t kc = 0;
+                PCH_TRY(dbscan_run(xyz + 3 * lo, cn, eps, min_samples, 0, nullptr, labels + lo, core ? core + lo : nullptr,
+                                   out_nclusters, ws, ws_bytes, s, &kc));
+                if (kc > 0 && offset > 0)
+                    PCH_LAUNCH("db_add_offset", db_add_offset_k, dim3((unsigned)ceil_div(cn, DB_THREADS)), dim3(DB_THREADS), 0, s,
+                               labels + lo, cn, offset);
+                offset += kc;                    // utils/tower_extraction.py:114-116
+            }
+            PCH_HIP_TRY(hipMemcpyAsync(out_nclusters, &offset, sizeof(int32_t), hipMemcpyHostToDevice, s));
+            PCH_HIP_TRY(hipStreamSynchronize(s));
+            if (k_host) *k_host = offset;
+            g_last.ws = nullptr;                 // no single grid is left to relabel on
+            return PCH_OK;
+        }
+        compressed = true;
+        int64_t* first_bad = reinterpret_cast<int64_t*>(w.meta + 12);
+        PCH_HIP_TRY(hipMemsetAsync(first_bad, 0xFF, sizeof(int64_t), s));
+        PCH_LAUNCH("db_first_bad", db_first_bad_k, dim3((unsigned)gstride), dim3(DB_THREADS), 0, s, xyz, n,
+                   reinterpret_cast<unsigned long long*>(first_bad));
+        PCH_HIP_TRY(hipMemsetAsync(w.meta + 6, 0, 6 * sizeof(uint32_t), s));
+        for (int axis = 0; axis < 3; ++axis) {
+            PCH_LAUNCH("dbc_axis_keys", dbc_axis_keys_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, n, axis, w.k0, w.v0);
+            PCH_TRY(radix_sort_pairs(w.k0, w.v0, w.k1, w.v1, n, 32, w.radix_ws, s));
+            const bool in1 = radix_sort_result_buffer(32) == 1;
+            const uint64_t* ksa = in1 ? w.k1 : w.k0;
+            const uint32_t* vsa = in1 ? w.v1 : w.v0;
+            PCH_LAUNCH("dbc_heads", dbc_heads_k, dim3(gn), dim3(DB_THREADS), 0, s, ksa, n, g.inv_cell, w.flag2);
+            PCH_TRY(scan_exclusive_u32(w.flag2, w.head, n, w.scan_ws, nullptr, s));
+            PCH_HIP_TRY(hipMemsetAsync(w.cell_start, 0, sizeof(uint32_t) * (size_t)(n + 8), s));
+            for (int phase = 0; phase < 2; ++phase)
+                PCH_LAUNCH("dbc_local", dbc_local_k, dim3(gn), dim3(DB_THREADS), 0, s, ksa, (const uint32_t*)w.flag2,
+                           (const uint32_t*)w.head, n, g.inv_cell, w.cell_box, phase, w.cid, w.cell_start, w.meta + 6);
+            PCH_TRY(scan_exclusive_u32(w.cell_start, w.cell_start, n, w.scan_ws, nullptr, s));
+            PCH_LAUNCH("dbc_comp", dbc_comp_k, dim3(gn), dim3(DB_THREADS), 0, s, vsa, (const uint32_t*)w.flag2,
+                       (const uint32_t*)w.head, (const uint32_t*)w.cid, (const uint32_t*)w.cell_start, n, axis, w.comp,
+                       w.meta + 9);
+        }
+        uint32_t back[8];                        // [0] status, [3..5] largest compressed index per axis, [6..7] first bad row
+        PCH_HIP_TRY(hipMemcpyAsync(back, w.meta + 6, sizeof(back), hipMemcpyDeviceToHost, s));
+        PCH_HIP_TRY(hipStreamSynchronize(s));
+        int64_t bad_row;
+        memcpy(&bad_row, &back[6], sizeof(bad_row));
+        if (bad_row >= 0) {                      // NaN / inf in a single fit: sklearn rejects it, everything stays noise
+            PCH_HIP_TRY(hipMemsetAsync(labels, 0xFF, sizeof(int32_t) * (size_t)n, s));
+            if (core) PCH_HIP_TRY(hipMemsetAsync(core, 0, (size_t)n, s));
+            PCH_HIP_TRY(hipMemsetAsync(out_nclusters, 0, sizeof(int32_t), s));
+            g_last.ws = nullptr;
+            return PCH_OK;
+        }
+        if (back[0] != 0) { set_error("compressed cell coordinates out of range"); return PCH_ERR_RANGE; }
+        g.mx = (int)back[3]; g.my = (int)back[4]; g.mz = (int)back[5];
+        g.bx = bits_for((uint64_t)g.mx + 1);
+        g.by = bits_for((uint64_t)g.my + 1);
+        g.bz = bits_for((uint64_t)g.mz + 1);
+        cellbits = g.bx + g.by + g.bz;
+        nbits = cellbits;
+        if (nbits > 64) {
+            set_error("cell key needs %d bits even with compressed coordinates (%lld isolated points?)", nbits, (long long)n);
+            return PCH_ERR_RANGE;
+        }
     }
 
-    const unsigned gn = (unsigned)ceil_div(n, DB_THREADS);
     PCH_HIP_TRY(hipMemsetAsync(w.meta + 6, 0, 4 * sizeof(uint32_t), s));
     const uint64_t* ks;
     // One workgroup per chunk only pays with enough chunks to fill the GPU (measured break-even near
@@ -1414,7 +1554,16 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
     const int sort_mode = db_sort_mode();
     const bool force_global = sort_mode == 2;
     const bool force_chunk = sort_mode == 1;
-    if (cellbits <= 32 && chunk_size <= CS_MAX_CHUNK && !force_global && (force_chunk || nchunks >= CS_MIN_CHUNKS)) {
+    if (compressed) {
+        PCH_HIP_TRY(hipMemsetAsync(w.chunk_bad, 0, sizeof(uint32_t) * (size_t)(nchunks + 1), s));
+        PCH_LAUNCH("db_keys_comp", db_keys_comp_k, dim3(gn), dim3(DB_THREADS), 0, s, (const uint32_t*)w.comp, n, g, w.k0,
+                   w.v0);
+        PCH_TRY(radix_sort_pairs(w.k0, w.v0, w.k1, w.v1, n, nbits, w.radix_ws, s));
+        const bool in1 = radix_sort_result_buffer(nbits) == 1;
+        ks = in1 ? w.k1 : w.k0;
+        const uint32_t* vs = in1 ? w.v1 : w.v0;
+        PCH_LAUNCH("db_gather", db_gather_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, ks, vs, n, w.pts, w.head);
+    } else if (cellbits <= 32 && chunk_size <= CS_MAX_CHUNK && !force_global && (force_chunk || nchunks >= CS_MIN_CHUNKS)) {
         // chunk-local path: one workgroup per chunk builds keys, sorts and gathers
         const int passes = cellbits <= 0 ? 0 : (cellbits + 7) / 8;
         const int dbits = passes ? (cellbits + passes - 1) / passes : 1;

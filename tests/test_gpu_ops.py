@@ -548,3 +548,36 @@ def test_decimate_is_a_sample_without_replacement(cuda, n, k):
         assert share.min() > 0.05 and share.max() < 0.2
     with pytest.raises(ValueError):
         ops.decimate(dev, n + 1)
+
+
+@pytest.mark.parametrize("case", ["cauchy_single", "cauchy_chunked", "outlier_1e30", "two_blobs_1e9_apart", "line_of_isolated"])
+def test_dbscan_grids_beyond_the_64bit_key(cuda, oracle_clib, case):
+    """extent/eps far beyond what a 64-bit [chunk|cz|cy|cx] key can hold (round 1: PCH_ERR_RANGE for the whole call):
+    chunks are then fitted one by one with their own boxes, and a single fit falls back to per-axis compressed
+    cell coordinates - same labels as the all-pairs oracle."""
+    rng = np.random.default_rng(abs(hash(case)) % 2**32)
+    eps, ms, chunk = 0.5, 5, 0
+    if case == "cauchy_single":
+        X = rng.standard_cauchy((4000, 3)) * 50.0
+    elif case == "cauchy_chunked":
+        X, chunk = rng.standard_cauchy((6000, 3)) * 80.0, 700
+        X[1500] = [3e12, -2e12, 1e12]
+    elif case == "outlier_1e30":
+        X = np.vstack([rng.normal(0, 1.0, (1500, 3)), rng.normal([40, 0, 0], 1.0, (1500, 3)), [[1e30, -1e30, 1e29]],
+                       rng.uniform(-200, 200, (500, 3))])
+        eps, ms = 1.0, 10
+    elif case == "two_blobs_1e9_apart":
+        X = np.vstack([rng.normal(0, 0.05, (2000, 3)), rng.normal([1e9, 1e9, -1e9], 40.0, (2000, 3))])
+        eps, ms = 0.3, 50
+    else:
+        X = np.column_stack([np.arange(3000) * 1e6, np.zeros(3000), np.zeros(3000)])
+        X[100:140] = X[100] + rng.normal(0, 0.1, (40, 3))
+        eps, ms = 1.0, 8
+    X = X[rng.permutation(len(X))].astype(np.float32)
+    want = odb.dbscan_chunked(X, eps, ms, chunk, fit="c")
+    lab, core, k = ops.dbscan(_dev(X, cuda), eps, ms, chunk, want_core=True)
+    np.testing.assert_array_equal(lab.cpu().numpy(), want)
+    assert k == (want.max() + 1 if (want >= 0).any() else 0)
+    if chunk == 0:
+        _, wcore = odb.dbscan_fit_c(X, eps, ms)
+        np.testing.assert_array_equal(core.cpu().numpy(), wcore)
