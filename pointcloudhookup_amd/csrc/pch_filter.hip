@@ -338,6 +338,7 @@ __global__ __launch_bounds__(GF_THREADS) void gf_compact_k(
     __shared__ uint32_t excl_sh;
     __shared__ uint32_t box[GF_THREADS / 64][6];
     __shared__ unsigned long long masks[GF_THREADS / 64][GF_ROUNDS];      // survivors of every 64-point round
+    __shared__ uint32_t cum[GF_THREADS / 64][GF_ROUNDS + 1];
     __shared__ uint32_t tile_sh;
     if (WHICH == 1 && st->use_b == 0) return;
     // The look-back below waits for every tile in front of this one, so the tile order must be an
@@ -364,6 +365,13 @@ __global__ __launch_bounds__(GF_THREADS) void gf_compact_k(
         run += (uint32_t)__popcll(m);
     }
     if (l == 0) wtot[w] = run;
+    {   // survivors in the rounds in front of round l (cum[w][64] = the wave's total)
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t c = (uint32_t)__popcll(masks[w][l]);
+        const uint32_t incl = wave_scan_incl(c);
+        cum[w][l] = incl - c;
+        if (l == 63) cum[w][64] = incl;
+    }
     __syncthreads();
     const uint32_t T = wtot[0] + wtot[1] + wtot[2] + wtot[3];
     if (w == 0) {
@@ -378,34 +386,51 @@ __global__ __launch_bounds__(GF_THREADS) void gf_compact_k(
     }
     __syncthreads();
     if (T == 0) return;                                       // workgroup-uniform
-    // ---- survivors: the row (one 12-byte load) is only fetched for them
+    // ---- survivors: the row (one 12-byte load) is only fetched for them.  The wave's survivors are taken
+    // DENSELY - lane j of pass d handles survivor 64 d + j of the wave, found through the per-round counts
+    // and the position of its bit in the round's mask - so that every lane has a row in flight and
+    // consecutive lanes write consecutive output rows (a pass over the 64 rounds with the ~10 % surviving
+    // lanes active would leave most lanes idle and scatter the writes)
     struct Row3 { float x, y, z; };
     uint32_t woff = excl_sh;
     for (int w2 = 0; w2 < w; ++w2) woff += wtot[w2];
     uint32_t lo[3] = {0u, 0u, 0u}, hi[3] = {0u, 0u, 0u};      // lo holds ~ordered(min)
-    const uint64_t lt = lanemask_lt();
-#pragma unroll 4
-    for (int r = 0; r < GF_ROUNDS; ++r) {
-        const unsigned long long m = masks[w][r];
-        if ((m >> l) & 1ull) {
-            const int64_t i = seg + r * 64 + l;
-            const Row3 q = reinterpret_cast<const Row3*>(raw)[i];
-            const float v[3] = {q.x - cx, q.y - cy, q.z - cz};
-            const int64_t o = (int64_t)woff + (uint32_t)__popcll(m & lt);
-            out_points[3 * o + 0] = v[0];
-            out_points[3 * o + 1] = v[1];
-            out_points[3 * o + 2] = v[2];
-            if (out_index) out_index[o] = (int32_t)i;
-            if (fabsf(v[0]) < INFINITY && fabsf(v[1]) < INFINITY && fabsf(v[2]) < INFINITY) {   // NaN/inf rows
+    const uint32_t nw = wtot[w];
+#pragma unroll 2
+    for (uint32_t j = l; j < nw; j += 64) {
+        int r = 0;                                             // largest round with cum[r] <= j
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const uint32_t k = f32_ordered(v[a]);
-                    lo[a] = ~k > lo[a] ? ~k : lo[a];
-                    hi[a] = k > hi[a] ? k : hi[a];
-                }
+        for (int step = 32; step > 0; step >>= 1)
+            if (cum[w][r + step] <= j) r += step;
+        unsigned long long m = masks[w][r];
+        uint32_t k = j - cum[w][r];                            // the k-th set bit of that round's mask
+        int bit = 0;
+        uint32_t word = (uint32_t)m;
+        {
+            const uint32_t c = (uint32_t)__popc(word);
+            if (k >= c) { k -= c; word = (uint32_t)(m >> 32); bit = 32; }
+        }
+#pragma unroll
+        for (int half = 16; half > 0; half >>= 1) {
+            const uint32_t c = (uint32_t)__popc(word & ((1u << half) - 1u));
+            if (k >= c) { k -= c; word >>= half; bit += half; }
+        }
+        const int64_t i = seg + r * 64 + bit;
+        const Row3 q = reinterpret_cast<const Row3*>(raw)[i];
+        const float v[3] = {q.x - cx, q.y - cy, q.z - cz};
+        const int64_t o = (int64_t)woff + j;
+        out_points[3 * o + 0] = v[0];
+        out_points[3 * o + 1] = v[1];
+        out_points[3 * o + 2] = v[2];
+        if (out_index) out_index[o] = (int32_t)i;
+        if (fabsf(v[0]) < INFINITY && fabsf(v[1]) < INFINITY && fabsf(v[2]) < INFINITY) {   // NaN/inf rows
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const uint32_t kk = f32_ordered(v[a]);
+                lo[a] = ~kk > lo[a] ? ~kk : lo[a];
+                hi[a] = kk > hi[a] ? kk : hi[a];
             }
         }
-        woff += (uint32_t)__popcll(m);
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
