@@ -194,6 +194,9 @@ int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t min_samples,
  * map [nmap] int32 (device): new id per old id (-1 = drop).  labels [n] int32: in/out. */
 int pch_dbscan_relabel_i32(const int32_t* map, int32_t nmap, int64_t n, int32_t* labels,
                            void* ws, size_t ws_bytes, void* stream);
+/* Smallest core row of every cluster of that same last call (the row that gives a cluster its number in
+ * sklearn's sweep): out_rows [nclusters] int32, ascending.  Same workspace rule as the relabel call. */
+int pch_dbscan_first_core_rows_i32(int64_t n, int32_t* out_rows, void* ws, size_t ws_bytes, void* stream);
 
 /* First row of xyz [n,3] float32 that holds NaN or +-inf, -1 if every row is finite.
  * Replaces: sklearn's input validation inside DBSCAN.fit (check_array, ensure_all_finite), which

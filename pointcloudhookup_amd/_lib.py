@@ -50,6 +50,7 @@ _SIGS = {
     "pch_dbscan_set_sort_mode": (None, [C.c_int]),
     "pch_first_nonfinite_row_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pch_dbscan_relabel_i32": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _sz, _vp]),
+    "pch_dbscan_first_core_rows_i32": (C.c_int, [_i64, _vp, _vp, _sz, _vp]),
     "pch_dbscan_ws_bytes": (_sz, [_i64]),
     "pch_dbscan_f32": (C.c_int, [_vp, _i64, _f64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pch_segment_by_label_ws_bytes": (_sz, [_i64, _i32]),

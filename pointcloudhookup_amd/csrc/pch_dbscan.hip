@@ -1292,6 +1292,21 @@ __global__ __launch_bounds__(DB_THREADS) void db_remap_cells_k(int* __restrict__
     cell_label[c] = neu >= 0 ? neu : INT_BIG;              // a dropped cluster attracts no border points
 }
 
+// cluster id -> its smallest core row (the set bits of the row bitmap, in order)
+__global__ __launch_bounds__(DB_THREADS) void db_first_rows_k(const uint32_t* __restrict__ bits,
+                                                              const uint32_t* __restrict__ rank, int64_t nw,
+                                                              int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= nw) return;
+    uint32_t b = bits[i];
+    uint32_t c = rank[i];
+    while (b) {
+        const int t = __builtin_ctz(b);
+        b &= b - 1;
+        out[c++] = (int32_t)(i * 32 + t);
+    }
+}
+
 __global__ void db_finish_k(const uint32_t* __restrict__ total, int32_t* __restrict__ out_nclusters) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *out_nclusters = (int32_t)*total;
 }
@@ -1654,6 +1669,26 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
     if (k_host) PCH_TRY(peek_wait(k_host, sizeof(int32_t)));
     g_last.ws = ws; g_last.ws_bytes = ws_bytes; g_last.n = n; g_last.m = m; g_last.g = g;
     g_last.has_rowtab = rowtab != nullptr;
+    return PCH_OK;
+}
+
+extern "C" int pch_dbscan_first_core_rows_i32(int64_t n, int32_t* out_rows, void* ws, size_t ws_bytes, void* stream) {
+    PCH_DEVICE_GUARD(out_rows ? (const void*)out_rows : (const void*)ws);
+    PCH_REQUIRE(n >= 0, "bad argument");
+    if (n == 0) return PCH_OK;
+    if (g_last.ws != ws || g_last.ws_bytes != ws_bytes || g_last.n != n || ws == nullptr) {
+        set_error("pch_dbscan_first_core_rows_i32 must follow pch_dbscan_f32 of this thread on the same, untouched workspace");
+        return PCH_ERR_ARG;
+    }
+    PCH_REQUIRE(out_rows != nullptr, "null output");
+    Arena a(ws, ws_bytes);
+    DbWs w;
+    db_plan(a, n, w);
+    const int64_t nw = ceil_div(n, 32);
+    const uint32_t* bits = w.flag;
+    const uint32_t* wrank = w.flag + ((nw + 63) & ~int64_t(63));
+    PCH_LAUNCH("db_first_rows", db_first_rows_k, dim3((unsigned)ceil_div(nw, DB_THREADS)), dim3(DB_THREADS), 0,
+               (hipStream_t)stream, bits, wrank, nw, out_rows);
     return PCH_OK;
 }
 

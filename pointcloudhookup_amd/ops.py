@@ -247,6 +247,20 @@ def dbscan_relabel(labels, cluster_map):
     return labels
 
 
+def dbscan_first_core_rows(n, nclusters, device):
+    """Smallest core row of every cluster of the LAST ops.dbscan call of this thread (int32 [nclusters])."""
+    L = _lib.lib()
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ws = getattr(_tls, "ws", {}).get(key)
+    if ws is None:
+        raise RuntimeError("dbscan_first_core_rows must follow ops.dbscan on this thread")
+    out = torch.empty((int(nclusters),), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.pch_dbscan_first_core_rows_i32(int(n), _ptr(out), _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
 def set_dbscan_sort_mode(mode):
     """Cell sort of ops.dbscan: "auto" (by chunk count), "chunk" (one workgroup per chunk) or "global"
     (one radix sort).  Same results either way; tests compare them."""

@@ -129,6 +129,11 @@ class HipFit:
         self.labels, core, k = ops.dbscan(points, self.eps, self.min_samples, 0, want_core=True)
         return self.labels, core.bool(), k
 
+    def first_core_rows(self, k):
+        """local row of the first core point of every cluster (what numbers the clusters)"""
+        from . import ops
+        return ops.dbscan_first_core_rows(self.labels.numel(), k, self.labels.device).long()
+
     def relabel(self, cluster_map):
         from . import ops
         cmap = torch.as_tensor(cluster_map, dtype=torch.int32, device=self.labels.device)
@@ -154,7 +159,8 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
     """Global DBSCAN of a cloud that is spread over the ranks as x-tiles with a halo of at least 2*eps.
 
     points : [n,3] float32 points of THIS rank's tile, halo included (device tensor for the HIP fit)
-    rows   : [n] int64 global row of every point (its index in the whole cloud; defines the cluster numbering)
+    rows   : [n] int64 global row of every point (its index in the whole cloud; defines the cluster numbering),
+             ASCENDING (the tile keeps the cloud's order)
     own    : [n] bool, True for the points this rank reports (x inside its own tile)
     x_lo, x_hi : this rank's own x-range [x_lo, x_hi)
     halo   : width of the overlap on either side (default and minimum 2*eps); every rank must use the same
@@ -171,16 +177,24 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
     labels, core, k = fit.fit(points)
     k = int(k)
     single = not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1
-    rows_h = torch.as_tensor(rows).cpu().to(torch.int64)
-    lab_h = torch.as_tensor(labels).cpu().to(torch.int64)
-    core_h = torch.as_tensor(core).cpu().bool()
-    x_h = torch.as_tensor(points)[:, 0].cpu()
-    # smallest global core row of every local cluster
-    minrow = torch.full((max(k, 1),), torch.iinfo(torch.int64).max, dtype=torch.int64)
-    cm = core_h & (lab_h >= 0)
-    if cm.any():
-        minrow.scatter_reduce_(0, lab_h[cm], rows_h[cm], reduce="amin")
-    minrow = minrow[:k]
+    # bookkeeping stays where the points are (device tensors with the HIP fit): only the per-cluster table and
+    # the pairs of the core points near the tile edges ever leave the device
+    pts_t = torch.as_tensor(points)
+    wdev = pts_t.device
+    rows_d = torch.as_tensor(rows).to(wdev, torch.int64)
+    lab_d = torch.as_tensor(labels).to(wdev, torch.int64)
+    core_d = torch.as_tensor(core).to(wdev).bool()
+    x_d = pts_t[:, 0]
+    # smallest global core row of every local cluster.  `rows` ascends with the local row, so it is the global
+    # row of the cluster's first local core point - which the fit knows (it numbers the clusters by it)
+    cm = core_d & (lab_d >= 0)
+    if hasattr(fit, "first_core_rows"):
+        minrow = rows_d[fit.first_core_rows(k)].cpu() if k else torch.zeros(0, dtype=torch.int64)
+    else:
+        minrow = torch.full((max(k, 1),), torch.iinfo(torch.int64).max, dtype=torch.int64, device=wdev)
+        if k:
+            minrow.scatter_reduce_(0, lab_d[cm], rows_d[cm], reduce="amin")
+        minrow = minrow[:k].cpu()
     if single:
         order = torch.argsort(minrow)
         cmap = torch.empty(k, dtype=torch.int64)
@@ -189,21 +203,39 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     comm_dev = torch.device("cpu")
     if dist.get_backend(group) == "nccl":                 # RCCL moves device buffers (a few KB..MB over xGMI)
-        comm_dev = torch.as_tensor(points).device
-    # core points that another tile also holds: everything outside [x_lo + halo, x_hi - halo)
+        comm_dev = wdev
     halo = 2.0 * float(eps) if halo is None else float(halo)
     if halo < 2.0 * float(eps):
         raise ValueError("halo must be at least 2*eps")
-    edge = cm & ((x_h < float(x_lo) + halo) | (x_h >= float(x_hi) - halo))
-    pairs = torch.stack([rows_h[edge], lab_h[edge]], dim=1)           # (global row, LOCAL cluster id)
+    if float(x_hi) - float(x_lo) < halo:
+        raise ValueError("a tile must be at least one halo wide (only neighbouring tiles are matched)")
+    # Which pieces belong together?  Every true core-core edge that crosses the tile edge e has an endpoint within
+    # eps of e, and such a point has its exact core flag in BOTH tiles.  So it is enough that the left tile of every
+    # edge publishes the (global row, local cluster) pairs of its core points with x in [e - eps, e + eps); the right
+    # tile looks those rows up in its own labels (on the device) and reports the distinct (left piece, right piece)
+    # links - a handful of pairs, whatever the number of shared points.
+    e_hi = float(x_hi)
+    strip = cm & (x_d >= e_hi - float(eps)) & (x_d < e_hi + float(eps))
+    if rank == world - 1:
+        strip = strip & False                              # no tile to the right
+    pairs = torch.stack([rows_d[strip], lab_d[strip]], dim=1)        # (global row, LOCAL cluster id)
     all_minrow = _gather_rows(minrow.reshape(-1, 1).to(comm_dev), group)
     all_pairs = _gather_rows(pairs.to(comm_dev), group)
     counts = [int(m.shape[0]) for m in all_minrow]
     offs = np.concatenate([[0], np.cumsum(counts)])
     total = int(offs[-1])
+    links = torch.zeros((0, 2), dtype=torch.int64, device=wdev)
+    if rank > 0 and all_pairs[rank - 1].shape[0] and rows_d.numel():
+        theirs = all_pairs[rank - 1].to(wdev)             # the left neighbour's strip at my lower edge
+        at = torch.searchsorted(rows_d, theirs[:, 0]).clamp(max=rows_d.numel() - 1)      # rows ascend
+        hit = (rows_d[at] == theirs[:, 0]) & cm[at]
+        if hit.any():
+            links = torch.unique(torch.stack([theirs[hit, 1] + int(offs[rank - 1]), lab_d[at[hit]] + int(offs[rank])],
+                                             dim=1), dim=0)
+    all_links = _gather_rows(links.to(comm_dev), group)
     if total == 0:
         return fit.relabel(torch.zeros(0, dtype=torch.int32)), 0
-    # union-find over all local clusters (uid = rank offset + local id): pieces sharing a core row are one cluster
+    # union-find over all local clusters (uid = rank offset + local id)
     parent = np.arange(total)
 
     def find(a):
@@ -212,14 +244,10 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
             a = parent[a]
         return a
 
-    pr = torch.cat([torch.stack([p[:, 0], p[:, 1] + int(offs[r])], dim=1) for r, p in enumerate(all_pairs)]).cpu().numpy()
-    if len(pr):
-        pr = pr[np.lexsort((pr[:, 1], pr[:, 0]))]
-        same = np.flatnonzero(pr[1:, 0] == pr[:-1, 0])
-        for i in same:
-            a, b = find(int(pr[i, 1])), find(int(pr[i + 1, 1]))
-            if a != b:
-                parent[max(a, b)] = min(a, b)
+    for u, v in torch.cat(all_links).cpu().numpy().reshape(-1, 2):
+        a, b2 = find(int(u)), find(int(v))
+        if a != b2:
+            parent[max(a, b2)] = min(a, b2)
     root = np.array([find(i) for i in range(total)])
     mr = torch.cat([m.reshape(-1) for m in all_minrow]).cpu().numpy()
     comp_min = np.full(total, np.iinfo(np.int64).max)
