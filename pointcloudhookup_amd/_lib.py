@@ -99,6 +99,10 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} not found - the HIP extension is not built. There is no CPU "
                 "fallback; run `make -C pointcloudhookup_amd/csrc` (needs hipcc).")
+        # PyTorch-ROCm ships its own HIP runtime (libamdhip64) and must be the one that loads it: had this
+        # library pulled in /opt/rocm's copy first, the process would hold two runtimes and ours would not
+        # know torch's allocations (hipPointerGetAttributes fails on them)
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)          # AttributeError if the .so is stale

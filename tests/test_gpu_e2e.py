@@ -247,3 +247,15 @@ def test_dbscan_relabel_redecides_border_points(cuda, oracle_clib):
     assert swapped[30] == 0                                            # smallest NEW id among its core neighbours
     dropped = ops.dbscan_relabel(labels, torch.tensor([5, -1], dtype=torch.int32, device=cuda)).cpu().numpy()
     assert (dropped[:30] == -1).all() and (dropped[31:] == 5).all() and dropped[30] == 5
+
+
+def test_build_then_smoke_in_one_process(cuda):
+    """__graft_entry__.build() loads libpch_hip.so before anything imports torch; PyTorch-ROCm brings its own
+    HIP runtime, and with /opt/rocm's copy loaded first the library did not know torch's allocations
+    (hipPointerGetAttributes failed in the device guard).  _lib.lib() therefore imports torch first."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
