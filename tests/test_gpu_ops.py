@@ -581,3 +581,62 @@ def test_dbscan_grids_beyond_the_64bit_key(cuda, oracle_clib, case):
     if chunk == 0:
         _, wcore = odb.dbscan_fit_c(X, eps, ms)
         np.testing.assert_array_equal(core.cpu().numpy(), wcore)
+
+
+# ------------------------------------------------------------------------------ order-free properties
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_voxel_set_is_invariant_under_permutation_within_a_chunk(cuda, seed):
+    """Open3D's output order is unspecified, so parity is defined on the SET of voxels: shuffling the points of a chunk
+    must leave (index, count) unchanged and move the means only by summation-order rounding."""
+    rng = np.random.default_rng(seed)
+    pts = rng.random((60000, 3)) * [80.0, 40.0, 12.0] + OFFSET
+    a = ops.voxel_downsample(_dev(pts, cuda), 0.3, 0)
+    b = ops.voxel_downsample(_dev(pts[rng.permutation(len(pts))], cuda), 0.3, 0)
+    np.testing.assert_array_equal(a[0].cpu().numpy(), b[0].cpu().numpy())
+    np.testing.assert_array_equal(a[2].cpu().numpy(), b[2].cpu().numpy())
+    np.testing.assert_allclose(a[1].cpu().numpy(), b[1].cpu().numpy(), rtol=0, atol=1e-8)
+    assert int(a[2].sum()) == len(pts)
+    # every mean lies in its own voxel, and voxelising the means again keeps every voxel (idempotence of the index)
+    lo = pts.min(0) - 0.15
+    np.testing.assert_array_equal(np.floor((a[1].cpu().numpy() - lo) / 0.3).astype(np.int32), a[0].cpu().numpy())
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_dbscan_partition_is_invariant_under_permutation(cuda, seed):
+    """sklearn's sweep numbers clusters by their smallest core index, so a permutation renumbers them - but the
+    PARTITION of the core points, the core mask and the noise set are order-free (border points may legitimately
+    switch between clusters they touch)."""
+    rng = np.random.default_rng(seed)
+    X = np.vstack([rng.normal([c, 50, 20], [2.5, 2.5, 8.0], (6000, 3)) for c in (40, 160, 300, 420)]
+                  + [np.column_stack([rng.uniform(0, 460, 6000), rng.uniform(0, 100, 6000), rng.uniform(0, 40, 6000)])]
+                  ).astype(np.float32)
+    perm = rng.permutation(len(X))
+    la, ca, ka = ops.dbscan(_dev(X, cuda), 8.0, 80, 0, want_core=True)
+    lb, cb, kb = ops.dbscan(_dev(X[perm], cuda), 8.0, 80, 0, want_core=True)
+    la, ca, lb, cb = la.cpu().numpy(), ca.cpu().numpy().astype(bool), lb.cpu().numpy(), cb.cpu().numpy().astype(bool)
+    assert ka == kb
+    np.testing.assert_array_equal(ca[perm], cb)                        # same core points
+    np.testing.assert_array_equal(la[perm] == -1, lb == -1)            # same noise
+    pairs = np.unique(np.stack([la[perm][cb], lb[cb]], axis=1), axis=0)
+    assert len(pairs) == ka and len(np.unique(pairs[:, 0])) == ka and len(np.unique(pairs[:, 1])) == ka   # a bijection
+    # ids are dense and ordered by first core row in either order
+    for lab, core in ((la, ca), (lb, cb)):
+        first = [np.flatnonzero((lab == c) & core)[0] for c in range(ka)]
+        assert first == sorted(first)
+
+
+def test_ground_filter_is_idempotent_on_its_own_threshold(cuda):
+    """keep = z - cz > thr: filtering the kept points again with the SAME centroid and threshold keeps them all -
+    checked through the returned index / points relation on a 5 M-point tile."""
+    raw = synth_tile(cuda, 5_000_000)
+    gf = ops.ground_filter(raw, want_index=True)
+    c = torch.tensor(gf["centroid"], device=cuda)
+    z = raw[:, 2] - c[2]
+    assert int((z > float(gf["threshold"])).sum()) == gf["count"]
+    assert torch.equal(gf["points"], raw[gf["index"].long()] - c)
+    assert bool((gf["points"][:, 2] > float(gf["threshold"])).all())
+
+
+def synth_tile(cuda, n):
+    from pointcloudhookup_amd import synth
+    return synth.corridor_torch(n, seed=synth.SEED0 + 9, kind="corridor", offset=True, device=cuda, dtype=torch.float32)
