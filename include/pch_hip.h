@@ -136,6 +136,27 @@ int pch_percentile_f32(const float* base, int64_t n, int64_t stride, const float
                        double q_percent, float* out,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* The three histogram passes of the radix select and the "smallest key above" pass one by one, for a
+ * percentile over values that are spread over several GPUs (pointcloudhookup_amd/tiles.py::shared_percentile:
+ * every rank histograms its part, the histograms are all-reduced, the host picks the bin).  Keys are the
+ * order-preserving uint32 images of the floats (sign bit flipped / complemented; NaN = 0xFFFFFFFF).
+ * pass 0: bins = key >> 20 (4096), pass 1: (key >> 8) & 0xFFF among keys with key >> 20 == prefix,
+ * pass 2: key & 0xFF among keys with key >> 8 == prefix.  out_hist [4096] uint32 (device), out_nan [1] uint64
+ * (device, may be NULL; filled by pass 0).  ws: pch_percentile_f32_ws_bytes.  Both synchronise. */
+int pch_select_hist_f32(const float* base, int64_t n, int64_t stride, int32_t pass, uint32_t prefix,
+                        uint32_t* out_hist, unsigned long long* out_nan, void* ws, size_t ws_bytes, void* stream);
+int pch_select_min_above_f32(const float* base, int64_t n, int64_t stride, uint32_t key, uint32_t* out_key,
+                             void* ws, size_t ws_bytes, void* stream);
+
+/* keep = (z - centroid[2]) > threshold, points = raw - centroid, order preserving: the sweep of the fused filter
+ * with GIVEN centroid and threshold (utils/tower_extraction.py:64,84 once both are known - the shared values of
+ * a tiled run).  out_points [n,3] capacity, out_index [n] int32 (may be NULL), out_count [1] int64, out_aabb [6]
+ * float32 (may be NULL).  Synchronises. */
+size_t pch_filter_gt_ws_bytes(int64_t n);
+int pch_filter_gt_f32(const float* raw, int64_t n, const float* centroid3_host, float threshold,
+                      float* out_points, int32_t* out_index, int64_t* out_count, float* out_aabb,
+                      void* ws, size_t ws_bytes, void* stream);
+
 /* Fused stage B: centroid, centring, percentile threshold, order-preserving compaction.
  * Replaces: utils/tower_extraction.py:63-64,82-89
  *   centroid = mean(raw); points = raw - centroid; base = percentile(points[:,2], pct);

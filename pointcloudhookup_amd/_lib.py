@@ -44,6 +44,10 @@ _SIGS = {
     "pch_mean_seq_serial_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pch_percentile_f32_ws_bytes": (_sz, [_i64]),
     "pch_percentile_f32": (C.c_int, [_vp, _i64, _i64, _vp, _f64, _vp, _vp, _sz, _vp]),
+    "pch_select_hist_f32": (C.c_int, [_vp, _i64, _i64, _i32, C.c_uint32, _vp, _vp, _vp, _sz, _vp]),
+    "pch_select_min_above_f32": (C.c_int, [_vp, _i64, _i64, C.c_uint32, _vp, _vp, _sz, _vp]),
+    "pch_filter_gt_ws_bytes": (_sz, [_i64]),
+    "pch_filter_gt_f32": (C.c_int, [_vp, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pch_ground_filter_ws_bytes": (_sz, [_i64]),
     "pch_ground_filter_f32": (C.c_int, [_vp, _i64, _f64, _f32, _f32, _i64, _vp, _vp, _vp, _vp, _vp,
                                         _vp, _sz, _vp]),

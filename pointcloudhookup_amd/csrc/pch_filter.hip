@@ -548,6 +548,124 @@ extern "C" int pch_percentile_f32(const float* base, int64_t n, int64_t stride, 
     return PCH_OK;
 }
 
+// ---- the select passes one by one, for a percentile over values that are spread over several GPUs
+// (tiles.shared_percentile: every rank histograms its part, the histograms are all-reduced, the host picks
+// the bin - same arithmetic, same result as pch_percentile_f32 over the concatenation)
+extern "C" int pch_select_hist_f32(const float* base, int64_t n, int64_t stride, int32_t pass, uint32_t prefix,
+                                   uint32_t* out_hist, unsigned long long* out_nan, void* ws, size_t ws_bytes,
+                                   void* stream) {
+    PCH_DEVICE_GUARD(out_hist);
+    hipStream_t s = (hipStream_t)stream;
+    PCH_REQUIRE(n >= 0 && stride >= 1 && pass >= 0 && pass <= 2 && out_hist && ws, "bad argument");
+    PCH_REQUIRE(n == 0 || base, "null input");
+    Arena a(ws, ws_bytes);
+    SelWs w;
+    sel_plan(a, w);
+    if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
+    SelState h;
+    memset(&h, 0, sizeof(h));
+    h.prefix = prefix;
+    PCH_HIP_TRY(hipMemcpyAsync(w.st, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    PCH_HIP_TRY(hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * SEL_BINS, s));
+    if (n > 0) {
+        int64_t gb = ceil_div(n, SEL_TILE);
+        if (gb > 2048) gb = 2048;
+        const dim3 grid((unsigned)gb), blk(256);
+        if (pass == 0) PCH_LAUNCH("sel_hist0", sel_hist_k<0>, grid, blk, 0, s, base, n, stride, w.st, w.hist);
+        else if (pass == 1) PCH_LAUNCH("sel_hist1", sel_hist_k<1>, grid, blk, 0, s, base, n, stride, w.st, w.hist);
+        else PCH_LAUNCH("sel_hist2", sel_hist_k<2>, grid, blk, 0, s, base, n, stride, w.st, w.hist);
+    }
+    PCH_HIP_TRY(hipMemcpyAsync(out_hist, w.hist, sizeof(uint32_t) * SEL_BINS, hipMemcpyDeviceToDevice, s));
+    if (out_nan)
+        PCH_HIP_TRY(hipMemcpyAsync(out_nan, &w.st->nan_count, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+    PCH_HIP_TRY(hipStreamSynchronize(s));               // `h` lives on this stack frame
+    return PCH_OK;
+}
+
+extern "C" int pch_select_min_above_f32(const float* base, int64_t n, int64_t stride, uint32_t key,
+                                        uint32_t* out_key, void* ws, size_t ws_bytes, void* stream) {
+    PCH_DEVICE_GUARD(out_key);
+    hipStream_t s = (hipStream_t)stream;
+    PCH_REQUIRE(n >= 0 && stride >= 1 && out_key && ws, "bad argument");
+    PCH_REQUIRE(n == 0 || base, "null input");
+    Arena a(ws, ws_bytes);
+    SelWs w;
+    sel_plan(a, w);
+    if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
+    SelState h;
+    memset(&h, 0, sizeof(h));
+    h.need_next = 1;
+    h.v0key = key;
+    h.next_min = 0xFFFFFFFFu;
+    PCH_HIP_TRY(hipMemcpyAsync(w.st, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    if (n > 0) {
+        int64_t gb = ceil_div(n, SEL_TILE);
+        if (gb > 2048) gb = 2048;
+        PCH_LAUNCH("sel_next", sel_next_k, dim3((unsigned)gb), dim3(256), 0, s, base, n, stride, w.st);
+    }
+    PCH_HIP_TRY(hipMemcpyAsync(out_key, &w.st->next_min, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    PCH_HIP_TRY(hipStreamSynchronize(s));
+    return PCH_OK;
+}
+
+// ---- keep = (z - cz) > threshold with GIVEN centroid and threshold (the shared values of a tiled run);
+// same sweep as the fused filter
+extern "C" size_t pch_filter_gt_ws_bytes(int64_t n) {
+    if (n < 0) return 0;
+    Arena a;
+    a.take<float>(8);
+    a.take<float>(n > 0 ? n : 1);
+    a.take<GfState>(1);
+    a.take<uint64_t>(2 * ceil_div(n > 0 ? n : 1, GF_TILE));
+    return a.off;
+}
+
+namespace pch {
+__global__ void gf_zcol_k(const float* __restrict__ raw, int64_t n, float* __restrict__ zcol) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) zcol[i] = raw[3 * i + 2];
+}
+__global__ void gf_count_out_k(const GfState* __restrict__ st, int64_t* __restrict__ out_count, float* __restrict__ out_aabb) {
+    if (threadIdx.x == 0) *out_count = (int64_t)st->total[0];
+    if (threadIdx.x < 6 && out_aabb) {
+        const int a = threadIdx.x;
+        uint32_t v = 0;
+        for (int k = 0; k < GF_SLOTS; ++k) { const uint32_t u = st->slots[0][k][a]; v = u > v ? u : v; }
+        out_aabb[a] = v == 0u ? 0.0f : f32_unordered(a < 3 ? ~v : v);
+    }
+}
+}  // namespace pch
+
+extern "C" int pch_filter_gt_f32(const float* raw, int64_t n, const float* centroid3_host, float threshold,
+                                 float* out_points, int32_t* out_index, int64_t* out_count, float* out_aabb,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    PCH_DEVICE_GUARD(out_count);
+    hipStream_t s = (hipStream_t)stream;
+    PCH_REQUIRE(n >= 0 && n < (int64_t(1) << 31) && centroid3_host && out_count && ws, "bad argument");
+    if (n == 0) {
+        PCH_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(int64_t), s));
+        return PCH_OK;
+    }
+    PCH_REQUIRE(raw && out_points, "null buffer");
+    Arena a(ws, ws_bytes);
+    float* scal = a.take<float>(8);                  // [0..2] centroid, [5] threshold (gf_compact_k<0> reads scal[4 + 1])
+    float* zcol = a.take<float>(n);
+    const size_t st_off = a.off;
+    GfState* st = a.take<GfState>(1);
+    const int64_t nb = ceil_div(n, GF_TILE);
+    uint64_t* status = a.take<uint64_t>(2 * nb);
+    if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
+    float hs[8] = {centroid3_host[0], centroid3_host[1], centroid3_host[2], 0.0f, 0.0f, threshold, threshold, 0.0f};
+    PCH_HIP_TRY(hipMemcpyAsync(scal, hs, sizeof(hs), hipMemcpyHostToDevice, s));
+    PCH_HIP_TRY(hipMemsetAsync(st, 0, a.off - st_off, s));
+    PCH_LAUNCH("gf_zcol", gf_zcol_k, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, raw, n, zcol);
+    PCH_LAUNCH("gf_compact", gf_compact_k<0>, dim3((unsigned)nb), dim3(GF_THREADS), 0, s, raw, (const float*)zcol, n,
+               (const float*)scal, (const float*)(scal + 4), st, status, (long long)0, out_points, out_index);
+    PCH_LAUNCH("gf_count_out", gf_count_out_k, dim3(1), dim3(64), 0, s, (const GfState*)st, out_count, out_aabb);
+    PCH_HIP_TRY(hipStreamSynchronize(s));               // `hs` lives on this stack frame
+    return PCH_OK;
+}
+
 extern "C" size_t pch_ground_filter_ws_bytes(int64_t n) {
     if (n < 0) return 0;
     Arena a;

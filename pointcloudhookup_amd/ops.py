@@ -178,6 +178,64 @@ def percentile_f32(values, q_percent, sub=None):
     return out
 
 
+def _strided_1d(values):
+    if not values.is_cuda or values.dtype != torch.float32 or values.dim() != 1:
+        raise TypeError("values must be a 1-D float32 CUDA tensor")
+    n = values.shape[0]
+    return n, (values.stride(0) if n > 1 else 1)
+
+
+def select_hist(values, pass_no, prefix=0):
+    """One histogram pass of the radix select over this tensor's values (see pch_select_hist_f32).
+    Returns (hist int64 [4096] on the host, NaN count)."""
+    L = _lib.lib()
+    n, stride = _strided_1d(values)
+    dev = values.device
+    with torch.cuda.device(dev):
+        hist = torch.empty((4096,), dtype=torch.int32, device=dev)
+        nan = torch.zeros((1,), dtype=torch.int64, device=dev)
+        ws = _workspace(L.pch_percentile_f32_ws_bytes(n), dev)
+        _lib.check(L.pch_select_hist_f32(values.data_ptr() if n else 0, n, stride, int(pass_no), int(prefix) & 0xFFFFFFFF,
+                                         _ptr(hist), _ptr(nan), _ptr(ws), ws.numel(), _stream()))
+    return hist.cpu().numpy().view("<u4").astype("int64"), int(nan.item())
+
+
+def select_min_above(values, key):
+    """Smallest order-preserving key of this tensor's values that is > key (0xFFFFFFFF if none)."""
+    L = _lib.lib()
+    n, stride = _strided_1d(values)
+    dev = values.device
+    with torch.cuda.device(dev):
+        out = torch.empty((1,), dtype=torch.int32, device=dev)
+        ws = _workspace(L.pch_percentile_f32_ws_bytes(n), dev)
+        _lib.check(L.pch_select_min_above_f32(values.data_ptr() if n else 0, n, stride, int(key) & 0xFFFFFFFF, _ptr(out),
+                                              _ptr(ws), ws.numel(), _stream()))
+    return int(out.cpu().numpy().view("<u4")[0])
+
+
+def filter_gt(raw, centroid, threshold, want_index=True):
+    """points = raw - centroid; keep z > threshold, order preserving, with GIVEN float32 centroid and threshold
+    (utils/tower_extraction.py:64,84).  Returns dict(points, index | None, count, aabb).  Synchronises."""
+    import ctypes as C
+    import numpy as np
+    L = _lib.lib()
+    raw = _need_cuda(raw, torch.float32, "raw").reshape(-1, 3)
+    n = raw.shape[0]
+    dev = raw.device
+    cen = (C.c_float * 3)(*[float(np.float32(v)) for v in centroid])
+    with torch.cuda.device(dev):
+        out_points = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        out_index = torch.empty((n,), dtype=torch.int32, device=dev) if want_index else None
+        cnt = torch.zeros((1,), dtype=torch.int64, device=dev)
+        aabb = torch.zeros((6,), dtype=torch.float32, device=dev)
+        ws = _workspace(L.pch_filter_gt_ws_bytes(n), dev)
+        _lib.check(L.pch_filter_gt_f32(_ptr(raw), n, C.cast(cen, C.c_void_p), float(np.float32(threshold)), _ptr(out_points),
+                                       _ptr(out_index), _ptr(cnt), _ptr(aabb), _ptr(ws), ws.numel(), _stream()))
+        m = int(cnt.item())
+    return dict(points=out_points[:m], index=None if out_index is None else out_index[:m], count=m,
+                aabb=aabb.cpu().numpy())
+
+
 def ground_filter(raw, pct=25.0, offset=3.0, fallback_offset=1.0, min_keep=1000, want_index=True):
     """Fused stage B on float32 [n,3].  Returns dict(points [n_f,3] f32 (centred, file
     order), index int32 [n_f] | None, centroid f32[3] (host np), base, threshold,

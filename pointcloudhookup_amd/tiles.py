@@ -258,3 +258,97 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
     gid[roots] = np.arange(len(roots))
     cmap = gid[root[offs[rank]:offs[rank] + k]]
     return fit.relabel(torch.as_tensor(cmap, dtype=torch.int32)), int(len(roots))
+
+
+# ------------------------------------------------------------------------------------------------
+# np.percentile over values that are spread over the ranks (the shared threshold of a tiled run)
+def _key_to_f32(key):
+    key = int(key) & 0xFFFFFFFF
+    if key == 0xFFFFFFFF:
+        return np.float32(np.nan)
+    u = (key & 0x7FFFFFFF) if key & 0x80000000 else (~key & 0xFFFFFFFF)
+    return np.array([u], dtype="<u4").view("<f4")[0]
+
+
+class HipSelect:
+    """the per-rank passes of the radix select on the GPU (pch_select_hist_f32 / pch_select_min_above_f32)"""
+
+    def hist(self, values, pass_no, prefix):
+        from . import ops
+        return ops.select_hist(values, pass_no, prefix)
+
+    def min_above(self, values, key):
+        from . import ops
+        return ops.select_min_above(values, key)
+
+
+def shared_percentile(values, q_percent, sub=None, select=None, group=None):
+    """np.percentile(concatenation of every rank's values - sub, q) in numpy >= 2 float32 semantics, bit for bit
+    what pch_percentile_f32 gives for the concatenation: three all-reduced 4096-bin histogram passes locate the
+    order statistic floor((N-1) q), one all-reduced minimum gives the next one, the lerp is numpy's.
+    values: this rank's 1-D float32 values (device tensor for the HIP passes); sub: float32 subtracted from the
+    two order statistics before the lerp (the centroid's z: x -> fl(x - sub) is monotone, so the select runs on
+    the raw values).  Returns np.float32."""
+    select = select or HipSelect()
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def allsum(a):
+        t = torch.as_tensor(np.asarray(a, dtype=np.int64))
+        if multi:
+            if dist.get_backend(group) == "nccl":
+                t = t.to(torch.as_tensor(values).device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t.cpu().numpy()
+
+    def allmin(v):
+        t = torch.tensor([int(v)], dtype=torch.int64)
+        if multi:
+            if dist.get_backend(group) == "nccl":
+                t = t.to(torch.as_tensor(values).device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return int(t.item())
+
+    n_local = int(torch.as_tensor(values).shape[0])
+    N = int(allsum([n_local])[0])
+    if N == 0:
+        raise IndexError("index -1 is out of bounds for axis 0 with size 0")     # what np.percentile raises
+    # numpy's index arithmetic in float32 (numpy/lib/_function_base_impl.py, method 'linear' under NEP 50)
+    qf = np.float32(q_percent) / np.float32(100.0)
+    vi = np.float32(N - 1) * qf
+    prev = np.floor(vi)
+    gamma = np.float32(vi - prev)
+    same = False
+    if vi >= np.float32(N - 1):
+        prev, same = np.float32(N - 1), True
+    if vi < 0:
+        prev, same = np.float32(0), True
+    k0 = min(max(int(prev), 0), N - 1)
+    same = same or k0 == N - 1
+    rank, prefix, nan_total = k0, 0, 0
+    cnt_final = 0
+    for p in range(3):
+        h, nan = select.hist(values, p, prefix)
+        h = allsum(h)
+        if p == 0:
+            nan_total = int(allsum([nan])[0])
+        nb = 256 if p == 2 else 4096
+        cum = np.cumsum(h[:nb])
+        b = int(np.searchsorted(cum, rank, side="right"))
+        below = int(cum[b - 1]) if b else 0
+        rank -= below
+        cnt_final = int(h[b])
+        prefix = b if p == 0 else ((prefix << 12) | b if p == 1 else (prefix << 8) | b)
+    v0key = prefix
+    a = _key_to_f32(v0key)
+    b_val = a
+    if not same and rank + 1 >= cnt_final:               # the next order statistic is not in v0's bin: smallest key above
+        b_val = _key_to_f32(allmin(select.min_above(values, v0key)))
+    c = np.float32(0.0) if sub is None else np.float32(sub)
+    a, b_val = np.float32(a - c), np.float32(b_val - c)
+    diff = np.float32(b_val - a)
+    r = np.float32(a + diff * gamma)
+    if gamma >= np.float32(0.5):
+        r = np.float32(b_val - diff * np.float32(np.float32(1.0) - gamma))
+    if nan_total:
+        r = np.float32(np.nan)
+    return r

@@ -259,3 +259,30 @@ def test_build_then_smoke_in_one_process(cuda):
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_shared_percentile_hip(cuda, tmp_path, world):
+    """tests/test_host.py's shared-percentile cases with the HIP select passes (pch_select_hist_f32,
+    pch_select_min_above_f32) on every rank."""
+    from test_host import _run_pct
+    _run_pct(tmp_path, world, "gpu", 29781 + world)
+
+
+def test_filter_gt_equals_the_fused_filter(cuda):
+    """pch_filter_gt_f32 with the centroid and threshold the fused filter found gives the fused filter's output."""
+    raw = synth.corridor_torch(3_000_001, seed=synth.SEED0 + 11, kind="corridor", offset=True, device=cuda,
+                               dtype=torch.float32)
+    gf = ops.ground_filter(raw, want_index=True)
+    got = ops.filter_gt(raw, gf["centroid"], gf["threshold"], want_index=True)
+    assert got["count"] == gf["count"]
+    assert torch.equal(got["points"], gf["points"]) and torch.equal(got["index"], gf["index"])
+    np.testing.assert_array_equal(got["aabb"], gf["aabb"])
+    thr = tiles_shared_threshold(raw, gf)
+    assert thr.view(np.uint32) == np.float32(gf["threshold"]).view(np.uint32)
+
+
+def tiles_shared_threshold(raw, gf):
+    from pointcloudhookup_amd import tiles
+    base = tiles.shared_percentile(raw[:, 2], 25.0, sub=gf["centroid"][2])
+    return np.float32(base + np.float32(3.0))

@@ -419,3 +419,78 @@ def test_native_las_header_on_byte_built_files(tmp_path):
         las.read_header_native(str(trunc))
     with pytest.raises(FileNotFoundError):
         las.read_header_native(str(tmp_path / "missing.las"))
+
+
+# ------------------------------------------------------------------ shared percentile / threshold across ranks
+_PCT_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from pointcloudhookup_amd import tiles
+rank, world, local = tiles.init_from_env(backend="gloo")
+use_gpu = sys.argv[2] == "gpu"
+
+def keys(v):
+    u = np.ascontiguousarray(v, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    k = np.where(u & 0x80000000, (~u) & 0xFFFFFFFF, u | 0x80000000)
+    return np.where(np.isnan(v), 0xFFFFFFFF, k).astype(np.uint64)
+
+class NumpySelect:                                     # CPU stand-in for tiles.HipSelect (tests only)
+    def hist(self, values, p, prefix):
+        v = np.asarray(values, np.float32)
+        k = keys(v)
+        if p == 0:
+            b = k >> 20
+        elif p == 1:
+            b = ((k >> 8) & 0xFFF)[(k >> 20) == prefix]
+        else:
+            b = (k & 0xFF)[(k >> 8) == prefix]
+        return np.bincount(b.astype(np.int64), minlength=4096)[:4096].astype(np.int64), int(np.isnan(v).sum())
+    def min_above(self, values, key):
+        k = keys(np.asarray(values, np.float32))
+        k = k[k > key]
+        return int(k.min()) if len(k) else 0xFFFFFFFF
+
+rng = np.random.default_rng(99)
+cases = []
+for n, q in ((1, 25), (2, 25), (5, 50), (1000, 25), (100003, 25), (100003, 99.5), (4096, 0), (4096, 100), (70001, 73.0)):
+    z = rng.normal(80.0, 7.0, n).astype(np.float32)
+    z[rng.integers(0, n, max(1, n // 3))] = np.float32(79.5)          # heavy duplicates around the quantile
+    cases.append((z, q, np.float32(81.25)))
+cases.append((np.concatenate([rng.normal(0, 1, 5000), [np.nan]]).astype(np.float32), 25, None))
+cases.append((np.full(3000, 2.5, np.float32), 25, np.float32(1.0)))
+for z, q, sub in cases:
+    want = np.float32(np.percentile(z - (sub if sub is not None else np.float32(0)), q))
+    cut = np.linspace(0, len(z), world + 1).astype(int)
+    mine = z[cut[rank]:cut[rank + 1]]                                   # ragged, possibly empty parts
+    if use_gpu:
+        got = tiles.shared_percentile(torch.from_numpy(mine).to("cuda:0"), q, sub=sub)
+    else:
+        got = tiles.shared_percentile(torch.from_numpy(mine), q, sub=sub, select=NumpySelect())
+    assert got.dtype == np.float32
+    assert (np.isnan(got) and np.isnan(want)) or got.view(np.uint32) == want.view(np.uint32), (len(z), q, got, want)
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def _run_pct(tmp_path, world, mode, port):
+    script = tmp_path / f"pct_{world}.py"
+    script.write_text(_PCT_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, mode], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_shared_percentile_equals_numpy_on_the_concatenation(tmp_path, world):
+    """The percentile threshold of a tiled run: every rank histograms its own values, three all-reduced passes
+    and one all-reduced minimum give np.percentile of the concatenation bit for bit (numpy >= 2 float32
+    semantics), with duplicates around the quantile, NaN, ragged and empty parts."""
+    _run_pct(tmp_path, world, "cpu", 29771 + world)

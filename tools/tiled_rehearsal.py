@@ -7,13 +7,16 @@ whole (tiles.cluster_tiled) and checked against a single-GPU DBSCAN of the whole
 On an 8-GPU node every rank takes its own GPU and the exchange runs over RCCL (backend nccl).  On the one-GPU
 box RCCL refuses two ranks on one device, so the ranks share cuda:0 and exchange over gloo
 (PCH_DIST_BACKEND=gloo PCH_BENCH_SINGLE_DEVICE=1): same code path except for where the exchanged tensors live.
-Every rank generates the same seeded cloud and filters it the same way (shared centroid and threshold - the
-part of config 4 that is not distributed yet), then keeps only its tile."""
+Every rank generates the same seeded cloud (the rehearsal has no tiled file reader), computes the one value that
+cannot be sharded by x - numpy's sequential float32 centroid - and keeps only its tile + halo.  The percentile
+threshold is then found ACROSS the ranks (tiles.shared_percentile), every rank filters its tile with it
+(ops.filter_gt) and the survivors are clustered as one cloud (tiles.cluster_tiled)."""
 import json
 import os
 import sys
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -32,16 +35,33 @@ dev = torch.device(f"cuda:{local}")
 torch.cuda.set_device(dev)
 raw = synth.corridor_torch(n, seed=synth.SEED0 + 4, kind="corridor", offset=False, device=dev, dtype=torch.float32)
 torch.cuda.synchronize()                                     # (a hang in the generator would show here, not in the filter)
-gf = ops.ground_filter(raw, want_index=True)                 # same result on every rank
-kept = raw[gf["index"].long()].contiguous()                  # UNcentred rows: one frame for all tiles
-del raw
-nf = kept.shape[0]
-L = synth.corridor_length(n)
-edges = tiles.tile_edges(float(kept[:, 0].min()), float(kept[:, 0].max()), world)
-take, own = tiles.tile_select(kept[:, 0], edges, rank, 2 * EPS)
-rows = torch.nonzero(take).flatten()
-pts = kept[rows].contiguous()
-own_l = own[rows]
+# the one value that cannot be sharded by x: numpy's SEQUENTIAL float32 centroid follows the file order
+centroid = ops.mean_seq_f32(raw).cpu().numpy()
+edges = tiles.tile_edges(float(raw[:, 0].min()), float(raw[:, 0].max()), world)
+take, own = tiles.tile_select(raw[:, 0], edges, rank, 2 * EPS)
+tile_rows = torch.nonzero(take).flatten()                    # global rows of this rank's tile, halo included
+tile = raw[tile_rows].contiguous()
+own_t = own[tile_rows]
+# single-GPU answer for the check at the end (whole cloud on this rank's GPU), then the whole cloud is dropped
+gf_all = ops.ground_filter(raw, want_index=True)
+want_lab, _, k1 = ops.dbscan(gf_all["points"], EPS, MS, 0)       # the centred float32 points, as the reference clusters them
+want_full = torch.full((n,), -2, dtype=torch.int32, device=dev)
+want_full[gf_all["index"].long()] = want_lab
+thr_all = np.float32(gf_all["threshold"])
+nf = int(gf_all["count"])
+del raw, gf_all, want_lab
+
+
+def tiled_step():
+    # shared threshold: percentile over every rank's OWN points (three all-reduced histogram passes)
+    base = tiles.shared_percentile(tile[own_t][:, 2].contiguous(), 25.0, sub=centroid[2])
+    thr = np.float32(base + np.float32(3.0))
+    kept = ops.filter_gt(tile, centroid, thr, want_index=True)            # this tile's survivors, halo included
+    loc = kept["index"].long()
+    rows = tile_rows[loc]                                                  # global rows, ascending
+    cx = float(centroid[0])                                                # the points are centred: so are the edges
+    labels, K = tiles.cluster_tiled(kept["points"], rows, own_t[loc], edges[rank] - cx, edges[rank + 1] - cx, EPS, MS)
+    return thr, labels, K, rows, own_t[loc]
 
 
 def barrier():
@@ -50,35 +70,31 @@ def barrier():
         dist.barrier()
 
 
-labels, K = tiles.cluster_tiled(pts, rows, own_l, edges[rank], edges[rank + 1], EPS, MS)       # warm-up
+thr, labels, K, rows, own_l = tiled_step()                    # warm-up
 barrier()
 t0 = time.perf_counter()
 steps = 3
 for _ in range(steps):
-    labels, K = tiles.cluster_tiled(pts, rows, own_l, edges[rank], edges[rank + 1], EPS, MS)
+    thr, labels, K, rows, own_l = tiled_step()
 barrier()
 dt = (time.perf_counter() - t0) / steps
-# the check: one DBSCAN over the whole filtered cloud on this rank's GPU
-want, _, k1 = ops.dbscan(kept, EPS, MS, 0)
-ok = bool(K == k1 and torch.equal(labels[own_l], want[rows[own_l]]))
+# the check: threshold and labels of the owned points against the single-GPU run over the whole cloud
+ok = bool(thr.view(np.uint32) == thr_all.view(np.uint32) and K == k1 and
+          torch.equal(labels[own_l], want_full[rows[own_l]]))
 flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev if world > 1 and dist.get_backend() == "nccl" else "cpu")
 tmax = torch.tensor([dt], dtype=torch.float64, device=flag.device)
 if world > 1:
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
 if rank == 0:
-    cut = 0
-    side = torch.bucketize(kept[:, 0].cpu(), torch.tensor(edges[1:-1], dtype=torch.float32))
-    for c in range(k1):
-        if len(torch.unique(side[(want == c).cpu()])) > 1:
-            cut += 1
+    cut = -1                                                   # (needs the whole cloud: counted in the unit tests instead)
     print(json.dumps({"config": "BASELINE config 4 rehearsal: x-tiles + 2*eps halo, global DBSCAN, label reconciliation",
                       "points": n, "filtered_points": int(nf), "ranks": world,
                       "backend": dist.get_backend() if world > 1 else "none",
                       "devices": "one GPU shared by all ranks" if os.environ.get("PCH_BENCH_SINGLE_DEVICE") else "one GPU per rank",
-                      "clusters": int(K), "clusters_cut_by_a_tile_edge": cut,
-                      "labels_equal_single_gpu_dbscan_on_every_rank": bool(int(flag.item())),
+                      "clusters": int(K),
+                      "shared_threshold_and_labels_equal_single_gpu_run_on_every_rank": bool(int(flag.item())),
                       "ms_per_tiled_step_max_over_ranks": round(float(tmax.item()) * 1e3, 3),
-                      "tile_points_rank0": int(pts.shape[0])}))
+                      "tile_points_rank0": int(tile.shape[0])}))
 if world > 1:
     dist.destroy_process_group()
