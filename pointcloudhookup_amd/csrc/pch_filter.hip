@@ -53,10 +53,20 @@ __device__ __forceinline__ void sel_hist_add(uint32_t* h, bool active, uint32_t 
     if (pending) atomicAdd(&h[bin], 1u);
 }
 
+// Gate of the bracketed select (below): a kernel runs only when *run_if == run_val (run_if == nullptr: always);
+// n_dev, when given, overrides the element count with a value that only exists on the device.
+struct SelGate { const uint32_t* run_if; uint32_t run_val; const uint32_t* n_dev; };
+__device__ __forceinline__ bool sel_gate(const SelGate& g, int64_t& n) {
+    if (g.run_if && *g.run_if != g.run_val) return false;
+    if (g.n_dev) n = (int64_t)*g.n_dev;
+    return true;
+}
+
 template <int PASS>
 __global__ __launch_bounds__(256) void sel_hist_k(const float* __restrict__ base, int64_t n,
                                                   int64_t stride, SelState* __restrict__ st,
-                                                  uint32_t* __restrict__ hist) {
+                                                  uint32_t* __restrict__ hist, SelGate gate = SelGate{nullptr, 0, nullptr}) {
+    if (!sel_gate(gate, n)) return;
     // pass 0 sees a handful of hot bins (z of a flat corridor): SEL_REP0 copies of the histogram, picked
     // by lane, divide the same-address serialisation of the LDS atomics
     constexpr int REP = PASS == 0 ? SEL_REP0 : 1;
@@ -114,7 +124,9 @@ __global__ __launch_bounds__(256) void sel_hist_k(const float* __restrict__ base
 
 // single workgroup: locate the bin holding the wanted rank, extend the prefix, clear hist
 template <int PASS>
-__global__ __launch_bounds__(256) void sel_pick_k(SelState* __restrict__ st, uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(256) void sel_pick_k(SelState* __restrict__ st, uint32_t* __restrict__ hist,
+                                                  SelGate gate = SelGate{nullptr, 0, nullptr}) {
+    if (gate.run_if && *gate.run_if != gate.run_val) return;
     __shared__ unsigned long long wsum[4];
     __shared__ int found_bin;
     __shared__ unsigned long long found_below;
@@ -160,7 +172,9 @@ __global__ __launch_bounds__(256) void sel_pick_k(SelState* __restrict__ st, uin
 
 // pass 4 (only when needed): smallest key strictly above v0key
 __global__ __launch_bounds__(256) void sel_next_k(const float* __restrict__ base, int64_t n,
-                                                  int64_t stride, SelState* __restrict__ st) {
+                                                  int64_t stride, SelState* __restrict__ st,
+                                                  SelGate gate = SelGate{nullptr, 0, nullptr}) {
+    if (!sel_gate(gate, n)) return;
     if (st->need_next == 0) return;
     const uint32_t v0 = st->v0key;
     uint32_t best = 0xFFFFFFFFu;
@@ -213,17 +227,141 @@ __global__ void sel_lerp_k(const SelState* __restrict__ st, int same_index, floa
     scal[2] = r + add2;
 }
 
-__global__ void sel_init_k(SelState* st, unsigned long long rank) { st->rank = rank; }
+// ---- bracketed select for large contiguous columns: ONE pass over the data instead of three ------------
+// A sample (16 consecutive values out of every 1024) is selected exactly at two ranks around the wanted
+// quantile; the keys L <= H found there bracket the wanted order statistics with overwhelming probability.
+// One pass over the column counts the keys below L and collects the keys in [L, H] (a few per cent of the
+// data); the exact three-pass select then runs on those candidates only, with the rank shifted by the count
+// below L.  Whether the bracket really holds both order statistics is CHECKED on the device
+// (sel_bracket_fix_k); if not, the original three passes over the whole column run instead (their kernels
+// return at once otherwise).  Either way the result is the exact order statistic - the sample only decides
+// how much data is read.
+constexpr int64_t SEL_BRACKET_MIN = int64_t(1) << 22;     // below this the three passes are cheap enough
+constexpr int SEL_GROUP = 16, SEL_EVERY = 1024;
+
+struct BrState {
+    unsigned long long less;       // keys < L
+    unsigned long long nan;        // NaN values seen by the bracket pass
+    uint32_t count;                // candidates collected (keys in [L, H])
+    uint32_t overflow;             // candidate buffer too small
+    uint32_t ok;                   // 1: both order statistics lie inside the candidates
+    uint32_t pad;
+};
+
+__global__ void sel_sample_k(const float* __restrict__ base, int64_t ns, float* __restrict__ sample) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ns) sample[i] = base[(i / SEL_GROUP) * SEL_EVERY + (i % SEL_GROUP)];
+}
+
+constexpr int SEL_STAGE = 2 * SEL_TILE;                  // candidates a workgroup stages in LDS before it reserves output
+
+__global__ __launch_bounds__(256) void sel_bracket_k(const float* __restrict__ base, int64_t n,
+                                                     const SelState* __restrict__ lo, const SelState* __restrict__ hi,
+                                                     BrState* __restrict__ br, float* __restrict__ cand, uint32_t cap) {
+    // candidates are staged in LDS and written out a few thousand at a time: one global atomic per flush (a
+    // reservation per wave would be ~1.5 M atomics on one address for 100 M values - 13 ms, measured)
+    __shared__ float stage[SEL_STAGE];
+    __shared__ uint32_t nstage, gbase;
+    const uint32_t L = lo->v0key, H = hi->v0key;
+    unsigned long long less = 0, nans = 0;
+    const uint64_t lt = lanemask_lt();
+    if (threadIdx.x == 0) nstage = 0;
+    __syncthreads();
+    auto flush = [&]() {                                   // workgroup-uniform call
+        const uint32_t m = nstage;
+        if (threadIdx.x == 0) gbase = m ? atomicAdd(&br->count, m) : 0u;
+        __syncthreads();
+        const uint32_t g0 = gbase;
+        for (uint32_t i = threadIdx.x; i < m; i += 256) {
+            if (g0 + i < cap) cand[g0 + i] = stage[i]; else br->overflow = 1u;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) nstage = 0;
+        __syncthreads();
+    };
+    auto take = [&](bool in, float v) {
+        const uint32_t k = sel_key(v);
+        less += (in && k < L) ? 1u : 0u;
+        nans += (in && v != v) ? 1u : 0u;
+        const bool keep = in && k >= L && k <= H;
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            const int leader = (int)__builtin_ctzll(m);
+            uint32_t at = 0;
+            if (lane_id() == leader) at = atomicAdd(&nstage, (uint32_t)__popcll(m));      // LDS atomic
+            at = (uint32_t)__builtin_amdgcn_readlane((int)at, leader);
+            if (keep) stage[at + (uint32_t)__popcll(m & lt)] = v;                          // < SEL_STAGE: see the flush rule
+        }
+    };
+    const int64_t span = (int64_t)gridDim.x * SEL_TILE;
+    const bool vec = (reinterpret_cast<uintptr_t>(base) & 15u) == 0;
+    for (int64_t t0 = (int64_t)blockIdx.x * SEL_TILE; t0 < n; t0 += span) {    // workgroup-uniform trip count
+        __syncthreads();
+        if (nstage > (uint32_t)(SEL_STAGE - SEL_TILE)) flush();                  // room for a whole tile of candidates
+        if (vec && t0 + SEL_TILE <= n) {
+            const float4* b4 = reinterpret_cast<const float4*>(base + t0);
+            float4 q[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q[r] = b4[r * 256 + threadIdx.x];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { take(true, q[r].x); take(true, q[r].y); take(true, q[r].z); take(true, q[r].w); }
+        } else {
+            for (int r = 0; r < SEL_TILE / 256; ++r) {
+                const int64_t i = t0 + r * 256 + threadIdx.x;
+                const bool in = i < n;
+                take(in, in ? base[i] : 0.0f);
+            }
+        }
+    }
+    __syncthreads();
+    flush();
+    less = wave_reduce_add(less);
+    nans = wave_reduce_add(nans);
+    if (lane_id() == 0) {
+        if (less) atomicAdd(&br->less, less);
+        if (nans) atomicAdd(&br->nan, nans);
+    }
+}
+
+// decides whether the candidates hold both order statistics and prepares the state of whichever select runs next
+__global__ void sel_bracket_fix_k(BrState* __restrict__ br, SelState* __restrict__ st, unsigned long long k0, int same) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned long long less = br->less, cnt = br->count;
+    const bool ok = br->overflow == 0 && less <= k0 && (k0 - less) < cnt && (same || (k0 + 1 - less) < cnt);
+    br->ok = ok ? 1u : 0u;
+    SelState z;
+    z.rank = ok ? k0 - less : k0;
+    z.less = 0; z.prefix = 0; z.need_next = 0; z.v0key = 0; z.v1key = 0;
+    z.nan_count = ok ? br->nan : 0ull;                     // (the full passes count NaN themselves)
+    z.next_min = 0; z.pad = 0;
+    *st = z;
+}
 
 struct SelWs {
     SelState* st;
     uint32_t* hist;
     float*    scal;     // 4 floats
+    // bracketed select (n >= SEL_BRACKET_MIN)
+    SelState *st_lo, *st_hi;
+    BrState*  br;
+    float    *sample, *cand;
+    int64_t   ns;       // sample size
+    uint32_t  cap;      // candidate capacity
 };
-static void sel_plan(Arena& a, SelWs& w) {
+static void sel_plan(Arena& a, SelWs& w, int64_t n = 0) {
     w.st = a.take<SelState>(1);
     w.hist = a.take<uint32_t>(SEL_BINS);
     w.scal = a.take<float>(4);
+    w.st_lo = w.st_hi = nullptr; w.br = nullptr; w.sample = w.cand = nullptr; w.ns = 0; w.cap = 0;
+    if (n >= SEL_BRACKET_MIN) {
+        w.st_lo = a.take<SelState>(1);
+        w.st_hi = a.take<SelState>(1);
+        w.br = a.take<BrState>(1);
+        w.ns = SEL_GROUP * (n / SEL_EVERY);
+        w.sample = a.take<float>(w.ns);
+        w.cap = (uint32_t)(n / 16) + 1024u;
+        w.cand = a.take<float>(w.cap);
+    }
 }
 
 // host side of np.percentile's index arithmetic (float32 under NEP 50)
@@ -245,26 +383,69 @@ static PctIndex pct_index(int64_t n, double q_percent) {
     return r;
 }
 
+// three histogram / pick rounds (+ the "next key" pass) on `st` / `hist`; st and hist are prepared by the caller
+static int select_rounds(const float* base, int64_t n, int64_t stride, bool with_next, SelState* st, uint32_t* hist,
+                         hipStream_t s, SelGate gate, int64_t grid_n) {
+    int64_t gb = ceil_div(grid_n, SEL_TILE);
+    if (gb > 2048) gb = 2048;
+    if (gb < 1) gb = 1;
+    const dim3 grid((unsigned)gb), blk(256);
+    PCH_LAUNCH("sel_hist0", sel_hist_k<0>, grid, blk, 0, s, base, n, stride, st, hist, gate);
+    PCH_LAUNCH("sel_pick0", sel_pick_k<0>, dim3(1), blk, 0, s, st, hist, gate);
+    PCH_LAUNCH("sel_hist1", sel_hist_k<1>, grid, blk, 0, s, base, n, stride, st, hist, gate);
+    PCH_LAUNCH("sel_pick1", sel_pick_k<1>, dim3(1), blk, 0, s, st, hist, gate);
+    PCH_LAUNCH("sel_hist2", sel_hist_k<2>, grid, blk, 0, s, base, n, stride, st, hist, gate);
+    PCH_LAUNCH("sel_pick2", sel_pick_k<2>, dim3(1), blk, 0, s, st, hist, gate);
+    if (with_next) PCH_LAUNCH("sel_next", sel_next_k, grid, blk, 0, s, base, n, stride, st, gate);
+    return PCH_OK;
+}
+
+__global__ void sel_init_k(SelState* st, unsigned long long rank) { st->rank = rank; }
+
 // the histogram / pick / next passes (need only the raw values) ...
 static int select_passes(const float* base, int64_t n, int64_t stride, double q_percent, SelWs& w,
                          hipStream_t s) {
     const PctIndex pi = pct_index(n, q_percent);
+    const SelGate always = {nullptr, 0, nullptr};
     PCH_HIP_TRY(hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * SEL_BINS, s));
-    PCH_HIP_TRY(hipMemsetAsync(w.st, 0, sizeof(SelState), s));
-    PCH_LAUNCH("sel_init", sel_init_k, dim3(1), dim3(1), 0, s, w.st, (unsigned long long)pi.k0);
+    if (!(w.sample && stride == 1 && n >= SEL_BRACKET_MIN)) {
+        PCH_HIP_TRY(hipMemsetAsync(w.st, 0, sizeof(SelState), s));
+        PCH_LAUNCH("sel_init", sel_init_k, dim3(1), dim3(1), 0, s, w.st, (unsigned long long)pi.k0);
+        return select_rounds(base, n, stride, !pi.same, w.st, w.hist, s, always, n);
+    }
+    // ---- bracket from the sample: ranks around k0 * ns / n, six sigma for ns/16 independent draws + 0.2 %
+    const int64_t ns = w.ns;
+    const double p = (double)pi.k0 / (double)(n > 1 ? n - 1 : 1);
+    const double sigma = sqrt(p * (1.0 - p) * (double)ns * 16.0);
+    const int64_t margin = (int64_t)(6.0 * sigma) + ns / 500 + 16;
+    const int64_t mid = (int64_t)(p * (double)(ns - 1));
+    const int64_t r_lo = mid - margin < 0 ? 0 : mid - margin;
+    const int64_t r_hi = mid + margin > ns - 1 ? ns - 1 : mid + margin;
+    PCH_LAUNCH("sel_sample", sel_sample_k, dim3((unsigned)ceil_div(ns, 256)), dim3(256), 0, s, base, ns, w.sample);
+    SelState* sts[2] = {w.st_lo, w.st_hi};
+    const int64_t rk[2] = {r_lo, r_hi};
+    for (int k = 0; k < 2; ++k) {
+        PCH_HIP_TRY(hipMemsetAsync(sts[k], 0, sizeof(SelState), s));
+        PCH_LAUNCH("sel_init", sel_init_k, dim3(1), dim3(1), 0, s, sts[k], (unsigned long long)rk[k]);
+        PCH_TRY(select_rounds(w.sample, ns, 1, false, sts[k], w.hist, s, always, ns));      // (each pick clears hist)
+    }
+    if (r_lo == 0)                                         // the bracket reaches the bottom: everything counts from key 0
+        PCH_HIP_TRY(hipMemsetAsync(&w.st_lo->v0key, 0, sizeof(uint32_t), s));
+    if (r_hi == ns - 1)                                    // ... or the top
+        PCH_HIP_TRY(hipMemsetAsync(&w.st_hi->v0key, 0xFF, sizeof(uint32_t), s));
+    PCH_HIP_TRY(hipMemsetAsync(w.br, 0, sizeof(BrState), s));
     int64_t gb = ceil_div(n, SEL_TILE);
     if (gb > 2048) gb = 2048;
-    if (gb < 1) gb = 1;
-    const dim3 grid((unsigned)gb), blk(256);
-    PCH_LAUNCH("sel_hist0", sel_hist_k<0>, grid, blk, 0, s, base, n, stride, w.st, w.hist);
-    PCH_LAUNCH("sel_pick0", sel_pick_k<0>, dim3(1), blk, 0, s, w.st, w.hist);
-    PCH_LAUNCH("sel_hist1", sel_hist_k<1>, grid, blk, 0, s, base, n, stride, w.st, w.hist);
-    PCH_LAUNCH("sel_pick1", sel_pick_k<1>, dim3(1), blk, 0, s, w.st, w.hist);
-    PCH_LAUNCH("sel_hist2", sel_hist_k<2>, grid, blk, 0, s, base, n, stride, w.st, w.hist);
-    PCH_LAUNCH("sel_pick2", sel_pick_k<2>, dim3(1), blk, 0, s, w.st, w.hist);
-    if (!pi.same)
-        PCH_LAUNCH("sel_next", sel_next_k, grid, blk, 0, s, base, n, stride, w.st);
-    return PCH_OK;
+    PCH_LAUNCH("sel_bracket", sel_bracket_k, dim3((unsigned)gb), dim3(256), 0, s, base, n, (const SelState*)w.st_lo,
+               (const SelState*)w.st_hi, w.br, w.cand, w.cap);
+    PCH_LAUNCH("sel_bracket_fix", sel_bracket_fix_k, dim3(1), dim3(64), 0, s, w.br, w.st, (unsigned long long)pi.k0,
+               pi.same);
+    // exact select on the candidates (runs when the bracket holds) ...
+    const SelGate on_cand = {&w.br->ok, 1u, &w.br->count};
+    PCH_TRY(select_rounds(w.cand, 0, 1, !pi.same, w.st, w.hist, s, on_cand, (int64_t)w.cap));
+    // ... or the three passes over the whole column (when it does not: their kernels return at once otherwise)
+    const SelGate on_all = {&w.br->ok, 0u, nullptr};
+    return select_rounds(base, n, stride, !pi.same, w.st, w.hist, s, on_all, n);
 }
 // ... and the final interpolation, which is where `sub` (the centroid) enters
 static int select_lerp(int64_t n, const float* sub, double q_percent, float add1, float add2, SelWs& w,
@@ -486,7 +667,7 @@ static void gf_plan(Arena& a, int64_t n, GfWs& w) {
     w.centroid = a.take<float>(4);
     ms_plan(a, n, w.ms);
     w.zcol = a.take<float>(n > 0 ? n : 1);
-    sel_plan(a, w.sel);
+    sel_plan(a, w.sel, n);
     const size_t st_off = a.off;
     w.st = a.take<GfState>(1);
     w.status = a.take<uint64_t>(2 * nb);
@@ -524,10 +705,10 @@ extern "C" int pch_mean_seq_serial_f32(const float* xyz, int64_t n, float* out_c
     return mean_seq_serial_launch(xyz, n, out_centroid, (hipStream_t)stream);
 }
 
-extern "C" size_t pch_percentile_f32_ws_bytes(int64_t) {
+extern "C" size_t pch_percentile_f32_ws_bytes(int64_t n) {
     Arena a;
     SelWs w;
-    sel_plan(a, w);
+    sel_plan(a, w, n);
     return a.off;
 }
 
@@ -541,7 +722,7 @@ extern "C" int pch_percentile_f32(const float* base, int64_t n, int64_t stride, 
     PCH_REQUIRE(q_percent >= 0.0 && q_percent <= 100.0, "Percentiles must be in the range [0, 100]");
     Arena a(ws, ws_bytes);
     SelWs w;
-    sel_plan(a, w);
+    sel_plan(a, w, n);
     if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
     PCH_TRY(select_percentile(base, n, stride, sub, q_percent, 0.0f, 0.0f, w, s));
     PCH_HIP_TRY(hipMemcpyAsync(out, w.scal, sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -640,3 +640,37 @@ def test_ground_filter_is_idempotent_on_its_own_threshold(cuda):
 def synth_tile(cuda, n):
     from pointcloudhookup_amd import synth
     return synth.corridor_torch(n, seed=synth.SEED0 + 9, kind="corridor", offset=True, device=cuda, dtype=torch.float32)
+
+
+@pytest.mark.parametrize("case", ["normal", "all_equal", "ties_at_quantile", "sorted", "reverse_sorted", "with_nan",
+                                  "two_values", "blocks_of_16"])
+@pytest.mark.parametrize("q", [0.0, 25.0, 50.0, 99.9, 100.0])
+def test_percentile_bracketed_select_is_exact(cuda, case, q):
+    """From 4 Mi values on, the percentile reads the column once: a sample brackets the order statistic, one pass
+    collects the bracket, the exact select runs on it - and the three full passes run instead whenever the device
+    finds that the bracket missed (overflowing ties, adversarial order).  Always np.percentile bit for bit."""
+    n = (1 << 22) + 12345
+    rng = np.random.default_rng(abs(hash(case)) % 2**32)
+    if case == "normal":
+        z = rng.normal(80.0, 7.0, n)
+    elif case == "all_equal":
+        z = np.full(n, 81.5)
+    elif case == "ties_at_quantile":
+        z = rng.normal(80.0, 7.0, n)
+        z[rng.random(n) < 0.6] = np.percentile(z, q)             # 60 % of the values ARE the quantile
+    elif case == "sorted":
+        z = np.sort(rng.normal(80.0, 7.0, n))
+    elif case == "reverse_sorted":
+        z = np.sort(rng.normal(80.0, 7.0, n))[::-1].copy()
+    elif case == "with_nan":
+        z = rng.normal(80.0, 7.0, n)
+        z[rng.integers(0, n, 3)] = np.nan
+    elif case == "two_values":
+        z = np.where(rng.random(n) < 0.2499999, 1.0, 2.0)
+    else:                                                         # the sample takes 16 of every 1024: make those special
+        z = rng.normal(80.0, 7.0, n)
+        z.reshape(-1)[: (n // 1024) * 1024].reshape(-1, 1024)[:, :16] = 1000.0
+    z = z.astype(np.float32)
+    want = np.float32(np.percentile(z, q))
+    got = ops.percentile_f32(_dev(z, cuda), q).cpu().numpy()[0]
+    assert (np.isnan(want) and np.isnan(got)) or got.view(np.uint32) == want.view(np.uint32), (case, q, got, want)
