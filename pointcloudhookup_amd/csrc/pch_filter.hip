@@ -53,20 +53,19 @@ __device__ __forceinline__ void sel_hist_add(uint32_t* h, bool active, uint32_t 
     if (pending) atomicAdd(&h[bin], 1u);
 }
 
-// Gate of the bracketed select (below): a kernel runs only when *run_if == run_val (run_if == nullptr: always);
-// n_dev, when given, overrides the element count with a value that only exists on the device.
-struct SelGate { const uint32_t* run_if; uint32_t run_val; const uint32_t* n_dev; };
-__device__ __forceinline__ bool sel_gate(const SelGate& g, int64_t& n) {
-    if (g.run_if && *g.run_if != g.run_val) return false;
-    if (g.n_dev) n = (int64_t)*g.n_dev;
-    return true;
+// Source switch of the bracketed select (below): when *ok is set the kernel works on the candidate buffer
+// (alt_base, *alt_n values, contiguous) instead of the column it was launched for - one launch serves either case.
+struct SelGate { const uint32_t* ok; const float* alt_base; const uint32_t* alt_n; };
+__device__ __forceinline__ void sel_gate(const SelGate& g, const float*& base, int64_t& n, int64_t& stride) {
+    if (g.ok && *g.ok) { base = g.alt_base; n = (int64_t)*g.alt_n; stride = 1; }
 }
 
 template <int PASS>
-__global__ __launch_bounds__(256) void sel_hist_k(const float* __restrict__ base, int64_t n,
+__global__ __launch_bounds__(256) void sel_hist_k(const float* __restrict__ base_in, int64_t n,
                                                   int64_t stride, SelState* __restrict__ st,
-                                                  uint32_t* __restrict__ hist, SelGate gate = SelGate{nullptr, 0, nullptr}) {
-    if (!sel_gate(gate, n)) return;
+                                                  uint32_t* __restrict__ hist, SelGate gate = SelGate{nullptr, nullptr, nullptr}) {
+    const float* base = base_in;
+    sel_gate(gate, base, n, stride);
     // pass 0 sees a handful of hot bins (z of a flat corridor): SEL_REP0 copies of the histogram, picked
     // by lane, divide the same-address serialisation of the LDS atomics
     constexpr int REP = PASS == 0 ? SEL_REP0 : 1;
@@ -124,9 +123,7 @@ __global__ __launch_bounds__(256) void sel_hist_k(const float* __restrict__ base
 
 // single workgroup: locate the bin holding the wanted rank, extend the prefix, clear hist
 template <int PASS>
-__global__ __launch_bounds__(256) void sel_pick_k(SelState* __restrict__ st, uint32_t* __restrict__ hist,
-                                                  SelGate gate = SelGate{nullptr, 0, nullptr}) {
-    if (gate.run_if && *gate.run_if != gate.run_val) return;
+__global__ __launch_bounds__(256) void sel_pick_k(SelState* __restrict__ st, uint32_t* __restrict__ hist) {
     __shared__ unsigned long long wsum[4];
     __shared__ int found_bin;
     __shared__ unsigned long long found_below;
@@ -171,10 +168,11 @@ __global__ __launch_bounds__(256) void sel_pick_k(SelState* __restrict__ st, uin
 }
 
 // pass 4 (only when needed): smallest key strictly above v0key
-__global__ __launch_bounds__(256) void sel_next_k(const float* __restrict__ base, int64_t n,
+__global__ __launch_bounds__(256) void sel_next_k(const float* __restrict__ base_in, int64_t n,
                                                   int64_t stride, SelState* __restrict__ st,
-                                                  SelGate gate = SelGate{nullptr, 0, nullptr}) {
-    if (!sel_gate(gate, n)) return;
+                                                  SelGate gate = SelGate{nullptr, nullptr, nullptr}) {
+    const float* base = base_in;
+    sel_gate(gate, base, n, stride);
     if (st->need_next == 0) return;
     const uint32_t v0 = st->v0key;
     uint32_t best = 0xFFFFFFFFu;
@@ -233,9 +231,8 @@ __global__ void sel_lerp_k(const SelState* __restrict__ st, int same_index, floa
 // One pass over the column counts the keys below L and collects the keys in [L, H] (a few per cent of the
 // data); the exact three-pass select then runs on those candidates only, with the rank shifted by the count
 // below L.  Whether the bracket really holds both order statistics is CHECKED on the device
-// (sel_bracket_fix_k); if not, the original three passes over the whole column run instead (their kernels
-// return at once otherwise).  Either way the result is the exact order statistic - the sample only decides
-// how much data is read.
+// (sel_bracket_fix_k); if not, the same three passes read the whole column instead of the candidates.
+// Either way the result is the exact order statistic - the sample only decides how much data is read.
 constexpr int64_t SEL_BRACKET_MIN = int64_t(1) << 22;     // below this the three passes are cheap enough
 constexpr int SEL_GROUP = 16, SEL_EVERY = 1024;
 
@@ -391,25 +388,29 @@ static int select_rounds(const float* base, int64_t n, int64_t stride, bool with
     if (gb < 1) gb = 1;
     const dim3 grid((unsigned)gb), blk(256);
     PCH_LAUNCH("sel_hist0", sel_hist_k<0>, grid, blk, 0, s, base, n, stride, st, hist, gate);
-    PCH_LAUNCH("sel_pick0", sel_pick_k<0>, dim3(1), blk, 0, s, st, hist, gate);
+    PCH_LAUNCH("sel_pick0", sel_pick_k<0>, dim3(1), blk, 0, s, st, hist);
     PCH_LAUNCH("sel_hist1", sel_hist_k<1>, grid, blk, 0, s, base, n, stride, st, hist, gate);
-    PCH_LAUNCH("sel_pick1", sel_pick_k<1>, dim3(1), blk, 0, s, st, hist, gate);
+    PCH_LAUNCH("sel_pick1", sel_pick_k<1>, dim3(1), blk, 0, s, st, hist);
     PCH_LAUNCH("sel_hist2", sel_hist_k<2>, grid, blk, 0, s, base, n, stride, st, hist, gate);
-    PCH_LAUNCH("sel_pick2", sel_pick_k<2>, dim3(1), blk, 0, s, st, hist, gate);
+    PCH_LAUNCH("sel_pick2", sel_pick_k<2>, dim3(1), blk, 0, s, st, hist);
     if (with_next) PCH_LAUNCH("sel_next", sel_next_k, grid, blk, 0, s, base, n, stride, st, gate);
     return PCH_OK;
 }
 
-__global__ void sel_init_k(SelState* st, unsigned long long rank) { st->rank = rank; }
+__global__ void sel_init_k(SelState* st, unsigned long long rank) {
+    SelState z;
+    z.rank = rank; z.less = 0; z.prefix = 0; z.need_next = 0; z.v0key = 0; z.v1key = 0; z.nan_count = 0;
+    z.next_min = 0; z.pad = 0;
+    *st = z;
+}
 
 // the histogram / pick / next passes (need only the raw values) ...
 static int select_passes(const float* base, int64_t n, int64_t stride, double q_percent, SelWs& w,
                          hipStream_t s) {
     const PctIndex pi = pct_index(n, q_percent);
-    const SelGate always = {nullptr, 0, nullptr};
+    const SelGate always = {nullptr, nullptr, nullptr};
     PCH_HIP_TRY(hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * SEL_BINS, s));
     if (!(w.sample && stride == 1 && n >= SEL_BRACKET_MIN)) {
-        PCH_HIP_TRY(hipMemsetAsync(w.st, 0, sizeof(SelState), s));
         PCH_LAUNCH("sel_init", sel_init_k, dim3(1), dim3(1), 0, s, w.st, (unsigned long long)pi.k0);
         return select_rounds(base, n, stride, !pi.same, w.st, w.hist, s, always, n);
     }
@@ -425,7 +426,6 @@ static int select_passes(const float* base, int64_t n, int64_t stride, double q_
     SelState* sts[2] = {w.st_lo, w.st_hi};
     const int64_t rk[2] = {r_lo, r_hi};
     for (int k = 0; k < 2; ++k) {
-        PCH_HIP_TRY(hipMemsetAsync(sts[k], 0, sizeof(SelState), s));
         PCH_LAUNCH("sel_init", sel_init_k, dim3(1), dim3(1), 0, s, sts[k], (unsigned long long)rk[k]);
         PCH_TRY(select_rounds(w.sample, ns, 1, false, sts[k], w.hist, s, always, ns));      // (each pick clears hist)
     }
@@ -440,12 +440,10 @@ static int select_passes(const float* base, int64_t n, int64_t stride, double q_
                (const SelState*)w.st_hi, w.br, w.cand, w.cap);
     PCH_LAUNCH("sel_bracket_fix", sel_bracket_fix_k, dim3(1), dim3(64), 0, s, w.br, w.st, (unsigned long long)pi.k0,
                pi.same);
-    // exact select on the candidates (runs when the bracket holds) ...
-    const SelGate on_cand = {&w.br->ok, 1u, &w.br->count};
-    PCH_TRY(select_rounds(w.cand, 0, 1, !pi.same, w.st, w.hist, s, on_cand, (int64_t)w.cap));
-    // ... or the three passes over the whole column (when it does not: their kernels return at once otherwise)
-    const SelGate on_all = {&w.br->ok, 0u, nullptr};
-    return select_rounds(base, n, stride, !pi.same, w.st, w.hist, s, on_all, n);
+    // exact select: on the candidates when the bracket holds, else over the whole column - the same launches either
+    // way, the kernels pick their source from br->ok
+    const SelGate src = {&w.br->ok, w.cand, &w.br->count};
+    return select_rounds(base, n, stride, !pi.same, w.st, w.hist, s, src, n);
 }
 // ... and the final interpolation, which is where `sub` (the centroid) enters
 static int select_lerp(int64_t n, const float* sub, double q_percent, float add1, float add2, SelWs& w,
