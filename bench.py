@@ -290,9 +290,36 @@ def main():
             os.environ.setdefault("PCH_OBB_WORKERS", str(min(16, os.cpu_count() or 1)))
             t0 = time.perf_counter()
             towers = pipeline.tower_table(cl)
-            out["tower_table"] = {"ms": round((time.perf_counter() - t0) * 1e3, 1), "clusters": K,
-                                  "towers": len(towers), "obb_workers": int(os.environ["PCH_OBB_WORKERS"]),
-                                  "note": "host stage D1-D3 (qhull boxes in worker processes), outside the timed region"}
+            first_ms = (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter()
+            towers = pipeline.tower_table(cl)
+            out["tower_table"] = {"ms": round((time.perf_counter() - t0) * 1e3, 1), "first_call_ms": round(first_ms, 1),
+                                  "clusters": K, "towers": len(towers), "obb_workers": int(os.environ["PCH_OBB_WORKERS"]),
+                                  "note": "host stage D1-D3, exact mode: qhull on every full cluster in worker processes "
+                                          "(the first call also starts them: ~1 s of scipy imports, which the drop-in "
+                                          "hides behind the file read), candidate directions priced by "
+                                          "pch_obb_search_f64; outside the timed region"}
+            # the same table in fast mode (device pre-filter + native candidate search), twice: the first call
+            # pays one-off allocations; centre / extent deltas of the towers both modes accept
+            try:
+                pipeline.tower_table(cl, obb_mode="fast")
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fast = pipeline.tower_table(cl, obb_mode="fast")
+                ms_fast = (time.perf_counter() - t0) * 1e3
+                ex = {t["label"]: t for t in towers}
+                both = [(ex[t["label"]], t) for t in fast if t["label"] in ex]
+                dc = sorted(float(np.abs(a["center"] - b["center"]).max()) for a, b in both)
+                de = sorted(float(np.abs(np.asarray(a["extent"]) - np.asarray(b["extent"])).max()) for a, b in both)
+                out["tower_table_fast"] = {
+                    "ms": round(ms_fast, 1), "towers": len(fast), "towers_in_both": len(both),
+                    "centre_delta_m": {"median": dc[len(dc) // 2] if dc else None, "max": dc[-1] if dc else None,
+                                       "above_1e-3": sum(d > 1e-3 for d in dc)},
+                    "extent_delta_m": {"median": de[len(de) // 2] if de else None, "max": de[-1] if de else None},
+                    "note": "opt-in (PCH_OBB_MODE=fast): pch_obb_shell_f32 + qhull on the kept ~1 % + "
+                            "pch_obb_min_boxes_f64; exact mode stays the default"}
+            except Exception as e:
+                out["tower_table_fast"] = {"error": str(e)}
         except Exception as e:
             out["tower_table"] = {"error": str(e)}
 

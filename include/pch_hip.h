@@ -238,6 +238,48 @@ int pch_segment_by_label(const int32_t* labels, const float* xyz, int64_t n,
                          int32_t nclusters, int32_t* out_perm, int64_t* out_offsets,
                          float* out_stats, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------ stage D1, fast mode
+ * The reference boxes every cluster with trimesh (utils/tower_extraction.py:137-139:
+ * trimesh.PointCloud(cluster_points).bounding_box_oriented): qhull's 3-D hull of the whole cluster, then a
+ * search over the hull's facet normals.  These two calls take the bandwidth part and the candidate search
+ * off the Python host; the hull itself stays with qhull (pointcloudhookup_amd/obb.py:boxes_fast).
+ *
+ * pch_obb_shell_f32: for every cluster of the grouped rows (perm / offsets as written by
+ * pch_segment_by_label) marks the points that can be vertices of the cluster's convex hull: a point
+ * strictly inside a tetrahedron spanned by points of the cluster (support points in 218 fixed directions
+ * and their mean) is dropped, everything else - a superset of the hull's vertices, about 1 % - is kept.
+ * Clusters of fewer than 2048 points are kept whole.
+ * xyz [*,3] float32; perm [n_grouped] int32; offsets [nclusters+1] int64 (device), offsets[nclusters] ==
+ * n_grouped; out_keep [n_grouped] uint8 in grouped order. */
+size_t pch_obb_shell_ws_bytes(int32_t nclusters);
+int pch_obb_shell_f32(const float* xyz, const int32_t* perm, const int64_t* offsets, int32_t nclusters,
+                      int64_t n_grouped, uint8_t* out_keep, void* ws, size_t ws_bytes, void* stream);
+/* HOST function (no device work): minimum-volume boxes of many convex hulls by trimesh's procedure
+ * (bounds.oriented_bounds: facet normals folded to a hemisphere, de-duplicated at 0.1 rad in spherical
+ * coordinates, per candidate the minimum-area rectangle of the projected vertices, smallest volume wins),
+ * on `nthreads` C++ threads (0: all cores).  All pointers are HOST pointers.
+ * verts [sum nv,3] float64 hull vertices, vert_offsets [nhulls+1]; tris [sum nt,3] int32 indices into the
+ * hull's own vertices (qhull's simplices), tri_offsets [nhulls+1]; sorted_extents: 0 = [rect_long,
+ * rect_short, normal_extent], 1 = ascending with permuted axes (current trimesh).
+ * out_to_origin [nhulls,16] row-major 4x4 (world -> box frame), out_extents [nhulls,3],
+ * out_status [nhulls]: 0 ok, 1 = no candidate (degenerate hull). */
+int pch_obb_min_boxes_f64(const double* verts, const int64_t* vert_offsets, const int32_t* tris,
+                          const int64_t* tri_offsets, int32_t nhulls, int32_t sorted_extents,
+                          int32_t nthreads, double* out_to_origin, double* out_extents, int32_t* out_status);
+
+/* HOST function: the search alone, for the exact mode.  The caller (pointcloudhookup_amd/obb.py) lets qhull
+ * build the hull of the FULL cluster and derives the candidate directions exactly as trimesh does; this call
+ * evaluates the box volume of every candidate and names the winner, which the caller then evaluates once
+ * more with the reference's own arithmetic - so the result is the python loop's, at 1/50 of its cost.
+ * angles [sum nc,2] float64 (theta, phi) in evaluation order, angle_offsets [nhulls+1].
+ * out_best [nhulls] int32: index of the first candidate of smallest volume (-1: none);
+ * out_volumes [sum nc]: box volume per candidate (inf: no rectangle) - a caller that wants the python loop's
+ * winner even when candidates tie in the last bits re-evaluates those that come within its tolerance of the
+ * smallest. */
+int pch_obb_search_f64(const double* verts, const int64_t* vert_offsets, const double* angles,
+                       const int64_t* angle_offsets, int32_t nhulls, int32_t nthreads,
+                       int32_t* out_best, double* out_volumes);
+
 /* ------------------------------------------------------------------ viewer helpers
  * Axis-aligned crop, bounds INCLUSIVE, order preserving:
  *   points[(x>=x0)&(x<=x1)&(y>=y0)&(y<=y1)&(z>=z0)&(z<=z1)]

@@ -62,6 +62,10 @@ _SIGS = {
     "pch_crop_aabb_ws_bytes": (_sz, [_i64]),
     "pch_crop_aabb_f64": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pch_decimate_f64": (C.c_int, [_vp, _i64, _i64, C.c_uint64, _vp, _vp, _vp]),
+    "pch_obb_shell_ws_bytes": (_sz, [_i32]),
+    "pch_obb_shell_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _sz, _vp]),
+    "pch_obb_search_f64": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "pch_obb_min_boxes_f64": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "pch_tower_clusters_ws_bytes": (_sz, [_i64, _i64, _i32]),
     "pch_tower_clusters_f32": (C.c_int, [_vp, _i64, _f64, _f32, _f32, _i64, _f64, _i32, _i64, _vp, _vp, _vp,
                                          _vp, _vp, _vp, _i64, _i32, _vp, _vp, _sz, _vp]),

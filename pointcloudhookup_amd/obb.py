@@ -88,21 +88,22 @@ def min_area_rectangle(xy):
     return t, rect
 
 
-def oriented_bounds(points, extent_order="unsorted"):
-    """Returns (to_origin 4x4, extents[3])."""
-    if extent_order not in _EXTENT_ORDERS:
-        raise ValueError(f"extent_order must be one of {_EXTENT_ORDERS}")
+def hull_candidates(points):
+    """(hull vertices [nv,3], candidate (theta, phi) [nc,2] in evaluation order) of one cluster."""
     verts, normals = hull_vertices_normals(points)
-    hom = np.column_stack((verts, np.ones(len(verts))))
-    best = None
-    for theta, phi in candidate_angles(normals):
-        to2d = _frame_to_z(theta, phi)
-        proj = (to2d @ hom.T).T[:, :3]
-        h = np.ptp(proj[:, 2])
-        t2, rect = min_area_rectangle(proj[:, :2])
-        vol = rect[0] * rect[1] * h
-        if best is None or vol < best[0]:
-            best = (vol, np.array([rect[0], rect[1], h]), to2d, t2)
+    return verts, candidate_angles(normals)
+
+
+def _candidate_box(hom, theta, phi):
+    """one candidate direction: (volume, extents, to2d, planar transform)"""
+    to2d = _frame_to_z(theta, phi)
+    proj = (to2d @ hom.T).T[:, :3]
+    h = np.ptp(proj[:, 2])
+    t2, rect = min_area_rectangle(proj[:, :2])
+    return rect[0] * rect[1] * h, np.array([rect[0], rect[1], h]), to2d, t2
+
+
+def _finish(hom, best, extent_order):
     _, extents, to2d, t2 = best
     rz = np.eye(4)
     rz[:2, :2] = t2[:2, :2]
@@ -118,6 +119,30 @@ def oriented_bounds(points, extent_order="unsorted"):
         to_origin = flip @ to_origin
         extents = extents[order]
     return to_origin, extents
+
+
+def bounds_from_candidates(verts, angles, extent_order="unsorted", shortlist=None):
+    """The search over the candidate directions.  ``shortlist`` (indices into ``angles``, ascending; from the
+    native search pch_obb_search_f64) restricts the loop to the candidates that can win: they are evaluated
+    with this module's own arithmetic and compared like the full loop compares, so the result is the full
+    loop's."""
+    if extent_order not in _EXTENT_ORDERS:
+        raise ValueError(f"extent_order must be one of {_EXTENT_ORDERS}")
+    hom = np.column_stack((verts, np.ones(len(verts))))
+    best = None
+    for theta, phi in (angles if shortlist is None else angles[shortlist]):
+        cand = _candidate_box(hom, theta, phi)
+        if best is None or cand[0] < best[0]:
+            best = cand
+    return _finish(hom, best, extent_order)
+
+
+def oriented_bounds(points, extent_order="unsorted"):
+    """Returns (to_origin 4x4, extents[3])."""
+    if extent_order not in _EXTENT_ORDERS:
+        raise ValueError(f"extent_order must be one of {_EXTENT_ORDERS}")
+    verts, angles = hull_candidates(points)
+    return bounds_from_candidates(verts, angles, extent_order)
 
 
 def bounding_box_oriented(points, extent_order="unsorted"):
@@ -140,9 +165,15 @@ _WORKERS = []
 def _boxed(args):
     points, extent_order = args
     try:
+        if extent_order == "__hull__":        # first half only: the native search runs in the caller
+            return hull_candidates(points), None
         return bounding_box_oriented(points, extent_order), None
     except Exception as e:                    # reported per cluster, like the serial loop does
         return None, e
+
+
+# candidates whose volume is within this (relative) of the smallest are decided by the python arithmetic
+_TIE = 1e-9
 
 
 class _Worker:
@@ -179,20 +210,69 @@ def _workers(n):
     return _WORKERS[:n]
 
 
-def boxes_of(clusters, extent_order="unsorted", workers=None):
+def boxes_of(clusters, extent_order="unsorted", workers=None, search=None):
     """Yields ((extents, transform), None) or (None, exception) for every (n_k,3) array in
     ``clusters``, in order.  workers: None -> PCH_OBB_WORKERS; unset: up to 8 worker processes once there are
-    at least 16 clusters (a 100 M-point tile has hundreds, ~25 ms of qhull each), none for small jobs.
-    The boxes are identical either way."""
+    at least 16 clusters (a 100 M-point tile has hundreds, ~10 ms of qhull each), none for small jobs.
+    search: "native" (default, env PCH_OBB_SEARCH) - qhull and the candidate directions per cluster as below,
+    then ONE call of pch_obb_search_f64 prices every direction of every cluster and only the directions within
+    1e-9 of the smallest volume (usually one) go through this module's python arithmetic; "python" - the loop
+    over all ~80 directions in python.  The boxes are identical either way."""
     import os
     clusters = list(clusters)
+    if extent_order not in _EXTENT_ORDERS:
+        raise ValueError(f"extent_order must be one of {_EXTENT_ORDERS}")
+    if search is None:
+        search = os.environ.get("PCH_OBB_SEARCH", "native")
+    if search not in ("native", "python"):
+        raise ValueError("search must be 'native' or 'python'")
     if workers is None:
         env = os.environ.get("PCH_OBB_WORKERS")
         workers = int(env) if env else (min(8, os.cpu_count() or 1) if len(clusters) >= 16 else 1)
-    if workers <= 1 or len(clusters) < 2:
-        for c in clusters:
-            yield _boxed((c, extent_order))
+    first = _per_cluster(clusters, "__hull__" if search == "native" else extent_order, workers)
+    if search == "python":
+        yield from first
         return
+    ok = [i for i, (h, e) in enumerate(first) if e is None]
+    winners = {}
+    if ok:
+        from . import ops
+        vo = np.cumsum([0] + [len(first[i][0][0]) for i in ok])
+        ao = np.cumsum([0] + [len(first[i][0][1]) for i in ok])
+        best, vol = ops.obb_search(np.concatenate([first[i][0][0] for i in ok]), vo,
+                                   np.concatenate([first[i][0][1].reshape(-1, 2) for i in ok]), ao)
+        for j, i in enumerate(ok):
+            if best[j] >= 0:
+                v = vol[ao[j]:ao[j + 1]]
+                winners[i] = np.flatnonzero(v <= v[best[j]] * (1.0 + _TIE))
+            else:
+                winners[i] = None              # no rectangle anywhere: the python loop reports it its way
+    for i, (h, e) in enumerate(first):
+        if e is not None:
+            yield None, e
+            continue
+        try:
+            to_origin, extents = bounds_from_candidates(h[0], h[1], extent_order, winners[i])
+            yield (extents, np.linalg.inv(to_origin)), None
+        except Exception as e2:
+            yield None, e2
+
+
+def prestart(workers=None):
+    """Starts the worker processes without waiting for them (their ~1 s of imports then runs beside the
+    caller's own work).  The drop-in calls this before it touches the file."""
+    import os
+    if workers is None:
+        env = os.environ.get("PCH_OBB_WORKERS")
+        workers = int(env) if env else min(8, os.cpu_count() or 1)
+    if workers > 1:
+        _workers(int(workers))
+
+
+def _per_cluster(clusters, what, workers):
+    """[_boxed((c, what)) for c in clusters], spread over worker processes when asked to."""
+    if workers <= 1 or len(clusters) < 2:
+        return [_boxed((c, what)) for c in clusters]
     import queue
     import threading
     tasks = queue.SimpleQueue()
@@ -207,9 +287,9 @@ def boxes_of(clusters, extent_order="unsorted", workers=None):
             except queue.Empty:
                 return
             try:
-                results[i] = w.ask((c, extent_order))
+                results[i] = w.ask((c, what))
             except Exception as e:            # a dead worker: compute here instead
-                results[i] = _boxed((c, extent_order)) if not isinstance(e, KeyboardInterrupt) else (None, e)
+                results[i] = _boxed((c, what)) if not isinstance(e, KeyboardInterrupt) else (None, e)
 
     threads = [threading.Thread(target=serve, args=(w,), daemon=True)
                for w in _workers(min(int(workers), len(clusters)))]
@@ -217,7 +297,56 @@ def boxes_of(clusters, extent_order="unsorted", workers=None):
         t.start()
     for t in threads:
         t.join()
-    yield from results
+    return results
+
+
+# ---- fast mode --------------------------------------------------------------------------------
+# Same published procedure, but qhull sees only the points the device could not prove to be strictly
+# inside the hull (pch_obb_shell_f32, about 1 % of a cluster) and the candidate search runs natively for
+# all clusters at once (pch_obb_min_boxes_f64).  Extents and centres agree with the exact mode to rounding
+# whenever qhull builds the same facets from the reduced input - mostly, not always,
+# and the sign of the two rectangle axes follows our own edge orientation, not qhull's.  Opt-in.
+def boxes_fast(points, perm, offsets, nclusters, extent_order="unsorted", nthreads=0):
+    """points float32 [N_f,3] (device), perm / offsets as returned by ops.segment_by_label.
+    Returns a list of ((extents, transform), None) or (None, exception) per cluster, in label order."""
+    import torch
+    from . import ops
+    if extent_order not in _EXTENT_ORDERS:
+        raise ValueError(f"extent_order must be one of {_EXTENT_ORDERS}")
+    K = int(nclusters)
+    if K == 0:
+        return []
+    keep = ops.obb_shell(points, perm, offsets, K)
+    pos = keep.nonzero().squeeze(1)                              # grouped positions, ascending
+    rows = perm.index_select(0, pos).long()
+    kept = points.index_select(0, rows).cpu().numpy().astype(np.float64)
+    bounds = torch.searchsorted(pos, offsets.to(pos.dtype)).cpu().numpy()
+    verts, tris, vo, to = [], [], [0], [0]
+    results = [None] * K
+    hulls = []
+    for k in range(K):
+        p = kept[bounds[k]:bounds[k + 1]]
+        try:
+            hull = ConvexHull(p, qhull_options="QbB Pp Qt")
+        except Exception as e:                                   # QhullError: too few / degenerate points
+            results[k] = (None, e)
+            continue
+        ids = np.sort(hull.vertices)
+        remap = np.empty(len(p), dtype=np.int32)
+        remap[ids] = np.arange(len(ids), dtype=np.int32)
+        verts.append(p[ids])
+        tris.append(remap[hull.simplices])
+        vo.append(vo[-1] + len(ids))
+        to.append(to[-1] + len(hull.simplices))
+        hulls.append(k)
+    if hulls:
+        T, E, S = ops.obb_min_boxes(np.concatenate(verts), vo, np.concatenate(tris), to,
+                                    extent_order == "trimesh_sorted", nthreads)
+        inv = np.linalg.inv(T)
+        for i, k in enumerate(hulls):
+            results[k] = ((E[i], inv[i]), None) if S[i] == 0 else \
+                (None, ValueError("degenerate hull: no candidate direction"))
+    return results
 
 
 if __name__ == "__main__":

@@ -411,6 +411,70 @@ def segment_by_label(labels, xyz, nclusters):
     return perm, offsets, stats[:K]
 
 
+# ---------------------------------------------------------------------------- stage D1, fast mode
+def obb_shell(xyz, perm, offsets, nclusters):
+    """uint8 [offsets[K]] in grouped order: 1 for the points of every cluster that can be vertices of its
+    convex hull (a superset of them), 0 for points strictly inside it (pch_obb_shell_f32)."""
+    L = _lib.lib()
+    xyz = _need_cuda(xyz, torch.float32, "xyz").reshape(-1, 3)
+    perm = _need_cuda(perm, torch.int32, "perm")
+    offsets = _need_cuda(offsets, torch.int64, "offsets")
+    K = int(nclusters)
+    if offsets.numel() != K + 1:
+        raise ValueError("offsets must hold nclusters + 1 entries")
+    dev = xyz.device
+    with torch.cuda.device(dev):
+        ng = int(offsets[K].item()) if K else 0
+        keep = torch.empty((ng,), dtype=torch.uint8, device=dev)
+        if ng:
+            ws = _workspace(L.pch_obb_shell_ws_bytes(K), dev)
+            _lib.check(L.pch_obb_shell_f32(_ptr(xyz), _ptr(perm), _ptr(offsets), K, ng, _ptr(keep), _ptr(ws),
+                                           ws.numel(), _stream()))
+    return keep
+
+
+def obb_min_boxes(verts, vert_offsets, tris, tri_offsets, sorted_extents=False, nthreads=0):
+    """Host arrays in, host arrays out: (to_origin [H,4,4], extents [H,3], status [H]) of H convex hulls
+    (pch_obb_min_boxes_f64)."""
+    import numpy as np
+    L = _lib.lib()
+    verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
+    tris = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+    vo = np.ascontiguousarray(vert_offsets, dtype=np.int64)
+    to = np.ascontiguousarray(tri_offsets, dtype=np.int64)
+    H = len(vo) - 1
+    if len(to) != H + 1 or (H >= 0 and (vo[-1] != len(verts) or to[-1] != len(tris))):
+        raise ValueError("offset tables do not match the vertex / triangle arrays")
+    T = np.zeros((max(H, 0), 4, 4), dtype=np.float64)
+    E = np.zeros((max(H, 0), 3), dtype=np.float64)
+    S = np.zeros((max(H, 0),), dtype=np.int32)
+    if H > 0:
+        _lib.check(L.pch_obb_min_boxes_f64(verts.ctypes.data, vo.ctypes.data, tris.ctypes.data, to.ctypes.data, H,
+                                           int(bool(sorted_extents)), int(nthreads), T.ctypes.data, E.ctypes.data,
+                                           S.ctypes.data))
+    return T, E, S
+
+
+def obb_search(verts, vert_offsets, angles, angle_offsets, nthreads=0):
+    """Host arrays: (best int32 [H], volumes float64 [sum nc]) - index of the candidate direction of smallest
+    box volume per hull, and the volume of every candidate (pch_obb_search_f64)."""
+    import numpy as np
+    L = _lib.lib()
+    verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
+    angles = np.ascontiguousarray(angles, dtype=np.float64).reshape(-1, 2)
+    vo = np.ascontiguousarray(vert_offsets, dtype=np.int64)
+    ao = np.ascontiguousarray(angle_offsets, dtype=np.int64)
+    H = len(vo) - 1
+    if len(ao) != H + 1 or vo[-1] != len(verts) or ao[-1] != len(angles):
+        raise ValueError("offset tables do not match the vertex / angle arrays")
+    best = np.full((max(H, 0),), -1, dtype=np.int32)
+    vol = np.zeros((len(angles),), dtype=np.float64)
+    if H > 0:
+        _lib.check(L.pch_obb_search_f64(verts.ctypes.data, vo.ctypes.data, angles.ctypes.data, ao.ctypes.data, H,
+                                        int(nthreads), best.ctypes.data, vol.ctypes.data))
+    return best, vol
+
+
 # ---------------------------------------------------------------------------- viewer helpers
 def crop_aabb(xyz, lo, hi, want_index=False):
     """points[(p >= lo).all(1) & (p <= hi).all(1)] for float64 [n,3], order preserving (test/kuangxuan.py:69-79).

@@ -47,17 +47,89 @@ def north_angle_deg(rotation):
 
 
 def tower_table(clusters, aspect_ratio_threshold=0.8, min_height=15.0, max_width=50.0, min_width=8,
-                duplicate_threshold=30.0, extent_order="unsorted", log=None, on_accept=None):
+                duplicate_threshold=30.0, extent_order="unsorted", log=None, on_accept=None, obb_mode="exact"):
     """Stage D1-D3 for every cluster, in ascending label order (the iteration order of the
     reference's ``set(all_labels) - {-1}``).  Returns list of dicts with the reference's keys
     (center, rotation, extent, height, width, north_angle, points) plus 'label' and
     'aspect_ratio'.  ``log`` receives the duplicate / failure messages, ``on_accept(tower)`` is
-    called for every accepted tower in order (the drop-in writes the tower LAS there)."""
+    called for every accepted tower in order (the drop-in writes the tower LAS there).
+    ``obb_mode``: "exact" (qhull on every full cluster, on the host) or "fast" (obb.boxes_fast: device
+    pre-filter + native candidate search; only the accepted towers' points are copied to the host)."""
+    if obb_mode not in ("exact", "fast"):
+        raise ValueError("obb_mode must be 'exact' or 'fast'")
     gf = clusters["ground"]
     k = int(clusters["nclusters"])
     towers, centers = [], []
     if k == 0:
         return towers
+    centroid = gf["centroid"]                                   # float32[3]
+    offsets = clusters["offsets"].cpu().numpy()
+    perm = clusters["perm"]
+    pts = gf["points"]
+    if obb_mode == "exact":
+        # one gather + one D2H copy for all clustered points (noise rows stay on the device)
+        rows = perm[: int(offsets[k])].long()
+        host_pts = pts.index_select(0, rows).cpu().numpy()
+        parts = [host_pts[offsets[label]:offsets[label + 1]] for label in range(k)]
+        # boxes of all clusters (PCH_OBB_WORKERS > 1: worker processes), consumed in label order
+        boxes = _obb.boxes_of(parts, extent_order)
+    else:
+        parts = None
+        boxes = _obb.boxes_fast(pts, perm, clusters["offsets"], k, extent_order)
+    # the reference's loop body (:131-215) per label; what it logs and accepts is replayed in order below, once
+    # the points of the accepted towers are on the host
+    events = []
+    for label, (box, err) in enumerate(boxes):
+        try:
+            if err is not None:
+                raise err
+            extents, transform = box
+            height = extents[2]
+            width = max(extents[0], extents[1])
+            aspect_ratio = height / width
+            if not (height > min_height and min_width < width < max_width
+                    and aspect_ratio > aspect_ratio_threshold):
+                continue
+            obb_center = transform[:3, 3] + centroid
+            dup = None
+            for c in centers:
+                d = np.linalg.norm(obb_center - c)
+                if d < duplicate_threshold:
+                    dup = d
+                    break
+            if dup is not None:
+                events.append(("log", f"⚠️ 跳过重复杆塔{label} (中心距: {dup:.1f}m)"))
+                continue
+            rot = transform[:3, :3]
+            tower = dict(label=label, center=obb_center, rotation=rot, extent=extents,
+                         height=height, width=width, aspect_ratio=aspect_ratio,
+                         north_angle=north_angle_deg(rot), points=None)
+            centers.append(obb_center)
+            events.append(("tower", tower))
+        except Exception as e:                                  # utils/tower_extraction.py:213-215
+            events.append(("log", f"⚠️ 簇{label} 处理失败: {str(e)}"))
+            continue
+    accepted = [ev[1] for ev in events if ev[0] == "tower"]
+    if parts is not None:
+        for t in accepted:
+            t["points"] = parts[t["label"]]
+    elif accepted:
+        spans = [(int(offsets[t["label"]]), int(offsets[t["label"] + 1])) for t in accepted]
+        pos = torch.cat([torch.arange(a, b, device=perm.device) for a, b in spans])
+        host_pts = pts.index_select(0, perm.index_select(0, pos).long()).cpu().numpy()
+        at = 0
+        for t, (a, b) in zip(accepted, spans):
+            t["points"] = host_pts[at:at + (b - a)]
+            at += b - a
+    for kind, item in events:
+        if kind == "log":
+            if log:
+                log(item)
+            continue
+        towers.append(item)
+        if on_accept:
+            on_accept(item)
+    return towers
     centroid = gf["centroid"]                                   # float32[3]
     offsets = clusters["offsets"].cpu().numpy()
     perm = clusters["perm"]

@@ -14,6 +14,10 @@ in tests/golden/refrun_nonfinite.npz: it logs the failure of that chunk and then
 ``finally: del chunk, clustering, chunk_labels`` (reference :120-122) raises UnboundLocalError out
 of extract_towers, because ``clustering`` was never bound.  "noise" is the behaviour its
 ``except`` clause evidently intended: the chunk stays unlabelled and the run continues.
+``OBB_MODE`` ("exact" | "fast", env PCH_OBB_MODE): "exact" hands every full cluster to qhull on the host
+(what trimesh does); "fast" filters the clusters on the device down to the points that can be hull vertices
+and searches the box natively (pointcloudhookup_amd/obb.py:boxes_fast) - same procedure, but qhull may merge
+facets differently on the reduced input, so a box can differ in the centimetres; see DESIGN.md section 11.
 """
 from __future__ import annotations
 
@@ -26,6 +30,8 @@ import numpy as np
 OBB_EXTENT_ORDER = os.environ.get("PCH_OBB_EXTENT_ORDER", "unsorted")
 DEVICE = os.environ.get("PCH_DEVICE", "cuda:0")
 CHUNK_FAILURE = os.environ.get("PCH_CHUNK_FAILURE", "reference")
+OBB_MODE = os.environ.get("PCH_OBB_MODE", "exact")
+PRESTART_BYTES = 100 << 20                             # LAS files from here on get worker processes early
 CHUNK_SIZE = 50000                                     # utils/tower_extraction.py:96
 
 
@@ -62,6 +68,9 @@ def extract_towers(
         import torch
         from .. import las as _las
         from .. import ops, pipeline
+        if OBB_MODE == "exact" and os.path.getsize(input_las_path) >= PRESTART_BYTES:
+            from .. import obb as _obb
+            _obb.prestart()                # the box workers import scipy while the file is being read
         dev = torch.device(DEVICE)
         hdr, XYZ = _las.read_device(input_las_path, dev)               # records decoded on the GPU
         raw = ops.cast_f32(ops.las_scale(XYZ, hdr.scales, hdr.offsets))
@@ -138,7 +147,7 @@ def extract_towers(
         progress(75 + int(15 * (label + 1) / max(k, 1)))
 
     pipeline.tower_table(clusters, aspect_ratio_threshold, min_height, max_width, min_width,
-                         duplicate_threshold, OBB_EXTENT_ORDER, log=log, on_accept=accept)
+                         duplicate_threshold, OBB_EXTENT_ORDER, log=log, on_accept=accept, obb_mode=OBB_MODE)
 
     # ---- xlsx (reference :221-231)
     if tower_rows:

@@ -494,3 +494,70 @@ def test_shared_percentile_equals_numpy_on_the_concatenation(tmp_path, world):
     and one all-reduced minimum give np.percentile of the concatenation bit for bit (numpy >= 2 float32
     semantics), with duplicates around the quantile, NaN, ragged and empty parts."""
     _run_pct(tmp_path, world, "cpu", 29771 + world)
+
+
+def test_native_box_search_equals_the_python_one():
+    """pch_obb_min_boxes_f64 is host code: given qhull's hull it must find the box obb.oriented_bounds finds
+    (extents and centre to rounding; the sign of the rectangle axes follows the edge orientation, which in
+    the python form is qhull's and arbitrary)."""
+    from scipy.spatial import ConvexHull
+    from pointcloudhookup_amd import obb, ops
+    rng = np.random.default_rng(8)
+    verts, tris, vo, to, clouds = [], [], [0], [0], []
+    for _ in range(24):
+        n = int(rng.integers(20, 1500))
+        q, _r = np.linalg.qr(rng.normal(size=(3, 3)))
+        p = (rng.normal(size=(n, 3)) * rng.uniform(1, 12, 3)).astype(np.float32).astype(np.float64) @ q.T
+        hull = ConvexHull(p, qhull_options="QbB Pp Qt")
+        ids = np.sort(hull.vertices)
+        remap = np.zeros(n, dtype=np.int64)
+        remap[ids] = np.arange(len(ids))
+        verts.append(p[ids]); tris.append(remap[hull.simplices])
+        vo.append(vo[-1] + len(ids)); to.append(to[-1] + len(hull.simplices))
+        clouds.append(p)
+    for order in obb._EXTENT_ORDERS:
+        for threads in (1, 4):
+            T, E, S = ops.obb_min_boxes(np.concatenate(verts), vo, np.concatenate(tris), to,
+                                        order == "trimesh_sorted", threads)
+            assert (S == 0).all()
+            for k, p in enumerate(clouds):
+                t_ref, e_ref = obb.oriented_bounds(p, order)
+                assert np.allclose(E[k], e_ref, atol=1e-10)
+                assert np.allclose(np.linalg.inv(T[k])[:3, 3], np.linalg.inv(t_ref)[:3, 3], atol=1e-10)
+                assert np.allclose(np.abs(T[k][:3, :3]), np.abs(t_ref[:3, :3]), atol=1e-10)
+                assert abs(np.linalg.det(T[k][:3, :3])) == pytest.approx(1.0, abs=1e-12)
+    # a flat "hull" has no volume: every candidate still gives a rectangle, the box has a zero extent
+    with pytest.raises(RuntimeError):
+        ops.obb_min_boxes(np.zeros((3, 3)), [0, 3], [[0, 1, 5]], [0, 1])
+
+
+def test_exact_mode_with_native_search_is_the_python_loop_bit_for_bit():
+    """boxes_of(search='native'): qhull sees the full cluster, pch_obb_search_f64 only names the winning
+    direction, the winner is evaluated by the python arithmetic - so nothing may differ from the python loop,
+    in either extent convention, with or without worker processes, including clouds whose best boxes tie
+    (a cuboid: several facet normals give the same box; the python loop decides those)."""
+    from pointcloudhookup_amd import obb
+    rng = np.random.default_rng(12)
+    clouds = []
+    for i in range(18):
+        n = int(rng.integers(300, 9000))
+        if i % 3 == 0:
+            p = rng.normal(size=(n, 3)) * [3, 3, 9]
+        elif i % 3 == 1:
+            p = rng.uniform(-1, 1, (n, 3)) * [4, 6, 20]
+        else:
+            p = np.round(rng.normal(size=(n, 3)) * [2, 3, 8], 2)          # 1 cm grid
+        clouds.append(p.astype(np.float32))
+    cuboid = np.array([[x, y, z] for x in (0.0, 4.0) for y in (0.0, 6.0) for z in (0.0, 20.0)])
+    clouds.append(np.vstack([cuboid, rng.uniform(0.5, 3.5, (200, 3))]).astype(np.float32))
+    clouds.append(np.zeros((10, 3), dtype=np.float32))                   # qhull refuses: same exception type
+    for order in obb._EXTENT_ORDERS:
+        want = list(obb.boxes_of(clouds, order, workers=1, search="python"))
+        for workers in (1, 3):
+            got = list(obb.boxes_of(clouds, order, workers=workers, search="native"))
+            for (a, ea), (b, eb) in zip(want, got):
+                assert type(ea) is type(eb)
+                if ea is None:
+                    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    with pytest.raises(ValueError):
+        list(obb.boxes_of(clouds, "unsorted", search="fast"))
