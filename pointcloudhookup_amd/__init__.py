@@ -4,7 +4,8 @@ ground-removal + tower-clustering hot path behind the reference's own call surfa
   csrc/                hand-written HIP kernels + the C ABI (include/pch_hip.h) -> libpch_hip.so
   _lib.py, ops.py      ctypes binding and tensor-level operators (no CPU fallback)
   pipeline.py          host orchestration of stages B-D0 on device tensors, tower acceptance / de-dup (D2-D3)
-  obb.py               per-cluster oriented boxes on the host (stage D1, scipy qhull, worker processes)
+  obb.py               per-cluster oriented boxes (stage D1): qhull in worker processes + native candidate search;
+                       opt-in fast mode with a device hull pre-filter
   las.py               LAS 1.x I/O: python header parser / host writer + the library's native reader / writer
   tiles.py             one process per GPU: tile streams, x-tiles with halo, label reconciliation (RCCL / gloo)
   synth.py             the seeded synthetic clouds of SURVEY.md section 8d

@@ -4,11 +4,16 @@
 trimesh is not a dependency; this module implements the same published procedure on
 scipy's qhull binding (the library trimesh itself calls): 3-D hull -> candidate normals
 (hemisphere folded, de-duplicated at 0.1 rad in spherical coordinates) -> per candidate a
-minimum-area rectangle of the projected hull -> smallest volume wins.  qhull sees the FULL
-cluster, like trimesh's: a hull pre-filter changes which near-coplanar facets qhull merges and
-moved a box centre by 1.3 cm in 1 of 12 trials, more than the 1e-3 m the
-north star allows.  Cost per 43 000-point cluster: ~10 ms for the 3-D hull, ~18 ms for the ~80
-candidate directions (one 2-D qhull call each over the ~60 hull vertices).
+minimum-area rectangle of the projected hull -> smallest volume wins.
+
+Exact mode (``boxes_of``, the default): qhull sees the FULL cluster, like trimesh's, in worker processes;
+the ~80-110 candidate directions of every cluster are priced by one native call (pch_obb_search_f64) and
+only the direction(s) that can win are evaluated by the python arithmetic below - bit for bit the result
+of the python loop (tests/test_host.py), at ~0.6 ms instead of ~18 ms per cluster on top of the ~7-10 ms
+hull.  Fast mode (``boxes_fast``, opt-in): the device drops the points strictly inside the hull first; qhull
+then lists the same hull's facets in another order, trimesh's "first normal of every 0.1 rad bucket" rule
+picks other candidates and in about 1 cluster of 6 another box of (almost) the same volume wins - centimetres
+apart, more than the 1e-3 m the north star allows.
 
 ``extent_order='unsorted'`` (default) returns extents as [rect_long, rect_short,
 normal_extent] - the behaviour the authors' recorded run shows
