@@ -75,6 +75,55 @@ __device__ __forceinline__ bool db_within2(const float4& q, const float4& p, con
     return db_within(q, p, g.eps2);
 }
 
+// ---- one query per lane against a staged tile of candidates --------------------------------
+// The tile holds candidates in pairs (x0 x1 | y0 y1 | z0 z1), so the float32 pre-filter of db_within2 runs on
+// packed two-wide arithmetic (v_pk_add/mul/fma_f32: same operations, same roundings) and without a branch per
+// candidate: the lane counts d <= eps2_lo and d < eps2_hi separately; only if the two counts differ - some
+// candidate fell into the 2^-20 guard band - is the tile counted again with the exact predicate.  The LDS reads
+// of four pairs are issued ahead of their arithmetic.  7 VALU instructions per test (before: 13 and a wait for
+// LDS per candidate).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct __attribute__((aligned(16))) DbPair { f32x2 x, y, z, pad; };
+
+__device__ __forceinline__ void db_tile_put(DbPair* __restrict__ tile, int l, const float4& p) {
+    float* f = reinterpret_cast<float*>(&tile[l >> 1]);
+    f[l & 1] = p.x; f[2 + (l & 1)] = p.y; f[4 + (l & 1)] = p.z;
+}
+__device__ __forceinline__ float4 db_tile_get(const DbPair* __restrict__ tile, int k) {
+    const float* f = reinterpret_cast<const float*>(&tile[k >> 1]);
+    float4 p;
+    p.x = f[k & 1]; p.y = f[2 + (k & 1)]; p.z = f[4 + (k & 1)]; p.w = 0.0f;
+    return p;
+}
+// nj candidates staged (padding beyond nj up to a multiple of 8 must be far away: +3e38); returns the number
+// of them within eps of q
+__device__ __forceinline__ int db_tile_count(const float4& q, const DbPair* __restrict__ tile, int nj,
+                                             const DbGrid& g) {
+    const f32x2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
+    const float lo = g.eps2_lo, hi = g.eps2_hi;
+    int c_lo = 0, c_hi = 0;
+    const int np = ((nj + 7) & ~7) >> 1;
+    for (int k = 0; k < np; k += 4) {
+        f32x2 px[4], py[4], pz[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { px[u] = tile[k + u].x; py[u] = tile[k + u].y; pz[u] = tile[k + u].z; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x2 dx = qx - px[u], dy = qy - py[u], dz = qz - pz[u];
+            f32x2 d = dx * dx;
+            d = __builtin_elementwise_fma(dy, dy, d);
+            d = __builtin_elementwise_fma(dz, dz, d);
+            c_lo += (d.x <= lo ? 1 : 0) + (d.y <= lo ? 1 : 0);
+            c_hi += (d.x < hi ? 1 : 0) + (d.y < hi ? 1 : 0);
+        }
+    }
+    if (c_lo != c_hi) {                                    // a candidate inside the guard band: exact recount
+        c_lo = 0;
+        for (int k = 0; k < nj; ++k) c_lo += db_within2(q, db_tile_get(tile, k), g) ? 1 : 0;
+    }
+    return c_lo;
+}
+
 // squared distance from a point to an axis-aligned box, same operation order as db_within;
 // never larger than the computed distance to any point inside the box (monotone rounding)
 __device__ __forceinline__ double db_box_d2(const float4& q, const float* __restrict__ box) {
@@ -595,7 +644,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
                                                         uint8_t* __restrict__ core_s,
                                                         uint32_t* __restrict__ cell_ncore) {
     __shared__ RowSet rows[DB_WAVES];
-    __shared__ __attribute__((aligned(16))) float4 tiles[DB_WAVES][64];
+    __shared__ DbPair tiles[DB_WAVES][32];
     __shared__ uint32_t seg_a[DB_WAVES][DB_SEGS], seg_b[DB_WAVES][DB_SEGS];
     const int c = blockIdx.x * DB_WAVES + wave_id();
     if (c >= m) return;
@@ -673,7 +722,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
         if (l == 0) cell_ncore[c] = ncore;
         return;
     }
-    float4* tile = tiles[wave_id()];
+    DbPair* tile = tiles[wave_id()];
     for (uint32_t q0 = s; q0 < e; q0 += 64) {              // 64 query points per round
         const bool valid = q0 + l < e;
         float4 Q;
@@ -693,13 +742,9 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
             P.x = P.y = P.z = 3.0e38f; P.w = 0.0f;         // padding: squared distance overflows to +inf
             if (l < nj) P = pts[j0 + l];
             __builtin_amdgcn_wave_barrier();
-            tile[l] = P;
+            db_tile_put(tile, l, P);
             __builtin_amdgcn_wave_barrier();
-            const int n8 = (nj + 7) & ~7;
-            for (int k = 0; k < n8; k += 8) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) count += db_within2(Q, tile[k + u], g) ? 1 : 0;
-            }
+            count += db_tile_count(Q, tile, nj, g);
             j0 += 64;
             active = __ballot(valid && count < g.min_samples);
         }
@@ -1046,6 +1091,84 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_k(DbGrid g, const float4*
     }
 }
 
+// ROUND 0, first half: one LANE per (cell, face direction).  A wave per cell walks one chain of dependent loads
+// (neighbour lookup -> counts and boxes -> roots -> first points) per cell; on sparse data (millions of cells of
+// a few dozen points) that chain, not arithmetic, is the whole cost.  Here 64 such chains are in flight per wave:
+// the lane finds its neighbour, compares boxes and parents and tries the first DB_PAIR_TRIES core points of either
+// cell against each other - adjacent cells almost always connect there - and unites on a hit.  Pairs it cannot
+// decide are flagged in face_todo[cell]; only those cells are looked at by the wave-wide db_union_face_k.
+constexpr int DB_PAIR_TRIES = 3;
+
+__global__ __launch_bounds__(DB_THREADS) void db_union_pairs_k(DbGrid g, const float4* __restrict__ pts,
+                                                               const uint32_t* __restrict__ cell_start,
+                                                               const uint64_t* __restrict__ cell_key, int m,
+                                                               const int2* __restrict__ rowtab,
+                                                               const uint8_t* __restrict__ core_s,
+                                                               const uint32_t* __restrict__ cell_ncore,
+                                                               const float* __restrict__ cell_box,
+                                                               int* __restrict__ parent,
+                                                               uint8_t* __restrict__ face_todo) {
+    const int64_t t = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
+    const int A = (int)(t >> 2), dir = (int)(t & 3);       // four lanes per cell: +x, +y, +z, idle
+    const bool lane_on = A < m && dir < 3;
+    bool undecided = false;
+    if (lane_on) {
+        const uint32_t ncoreA = cell_ncore[A];
+        if (ncoreA != 0) {
+            const uint64_t keyA = cell_key[A];
+            int B = -1;
+            if (dir == 0) {
+                if (A + 1 < m && cell_key[A + 1] == keyA + 1ull) B = A + 1;
+            } else {
+                const int2 run = rowtab[(int64_t)A * DB_ROWS + (dir == 1 ? 1 : 3)];
+                const uint64_t want = keyA + (dir == 1 ? (1ull << g.bx) : (1ull << (g.bx + g.by)));
+                for (int k = run.x; k < run.y; ++k)
+                    if (cell_key[k] == want) { B = k; break; }
+            }
+            if (B > A) {
+                const uint32_t nB = cell_ncore[B];
+                if (nB != 0) {
+                    float boxB[6];
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) boxB[a] = cell_box[6 * (int64_t)B + a];
+                    bool pend = !(db_boxbox_d2(cell_box + 6 * (int64_t)A, boxB) > g.eps2);
+                    if (pend) pend = parent[A] != parent[B];
+                    int rootA = A, rootB = B;
+                    if (pend) {
+                        rootA = uf_find(parent, A);
+                        rootB = uf_find(parent, B);
+                        pend = rootA != rootB;
+                    }
+                    if (pend) {
+                        const uint32_t as = cell_start[A], ae = cell_start[A + 1];
+                        const uint32_t bs = cell_start[B], be = cell_start[B + 1];
+                        const bool a_dense = ncoreA == (ae - as), b_dense = nB == (be - bs);
+                        float4 pb[DB_PAIR_TRIES];
+                        int nb = 0;
+                        for (uint32_t j = bs; j < be && nb < DB_PAIR_TRIES; ++j)
+                            if (b_dense || core_s[j]) pb[nb++] = pts[j];
+                        bool connected = false;
+                        int na = 0;
+                        for (uint32_t i = as; i < ae && na < DB_PAIR_TRIES && !connected; ++i) {
+                            if (!a_dense && !core_s[i]) continue;
+                            ++na;
+                            const float4 pa = pts[i];
+                            if (db_box_d2(pa, boxB) > g.eps2) continue;
+#pragma unroll
+                            for (int j = 0; j < DB_PAIR_TRIES; ++j)
+                                if (j < nb && db_within2(pa, pb[j], g)) connected = true;
+                        }
+                        if (connected) uf_union(parent, rootA, rootB);
+                        else undecided = true;
+                    }
+                }
+            }
+        }
+    }
+    const unsigned long long um = __ballot(undecided);
+    if (A < m && dir == 0) face_todo[A] = (uint8_t)((um >> (lane_id() & ~3)) & 7ull);
+}
+
 // ROUND 0 as its own kernel: the (up to) three face neighbours with a larger key are examined side
 // by side, 21 lanes each, so that the chain of dependent loads (neighbour lookup, roots, first
 // points) is walked once per cell instead of once per neighbour.  Adjacent dense cells connect at
@@ -1060,10 +1183,12 @@ __global__ __launch_bounds__(DB_THREADS) void db_union_face_k(DbGrid g, const fl
                                                               const uint8_t* __restrict__ core_s,
                                                               const uint32_t* __restrict__ cell_ncore,
                                                               const float* __restrict__ cell_box,
-                                                              int* __restrict__ parent) {
+                                                              int* __restrict__ parent,
+                                                              const uint8_t* __restrict__ face_todo) {
     __shared__ RowSet rows[DB_WAVES];
     const int A = blockIdx.x * DB_WAVES + wave_id();
     if (A >= m) return;
+    if (face_todo && face_todo[A] == 0) return;            // db_union_pairs_k has settled this cell's faces
     const uint32_t ncoreA = cell_ncore[A];
     if (ncoreA == 0) return;
     const int l = lane_id();
@@ -1636,9 +1761,19 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
                w.cell_acc);
     PCH_LAUNCH("db_cellfin", db_cellfin_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
                (const uint32_t*)w.cell_acc, m, w.cell_box, w.cell_min, w.parent, w.comp_min);
+    // face neighbours: lane-per-pair first (needs the row table), the wave-wide search for what that left open;
+    // the flags live in w.root, which nobody needs before db_compmin_k
+    const uint8_t* face_todo = nullptr;
+    if (rowtab) {
+        PCH_LAUNCH("db_union_pairs", db_union_pairs_k, dim3((unsigned)ceil_div(4 * (int64_t)m, DB_THREADS)),
+                   dim3(DB_THREADS), 0, s, g, (const float4*)w.pts, (const uint32_t*)w.cell_start,
+                   (const uint64_t*)w.cell_key, m, rowtab, (const uint8_t*)w.core_s, (const uint32_t*)w.cell_ncore,
+                   (const float*)w.cell_box, w.parent, reinterpret_cast<uint8_t*>(w.root));
+        face_todo = reinterpret_cast<const uint8_t*>(w.root);
+    }
     PCH_LAUNCH("db_union0", db_union_face_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
                (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, (const uint8_t*)w.core_s,
-               (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, w.parent);
+               (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, w.parent, face_todo);
     PCH_LAUNCH("db_flatten", db_flatten_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
                w.parent, m);
     PCH_LAUNCH("db_union1", db_union_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
