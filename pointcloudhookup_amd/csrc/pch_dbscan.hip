@@ -328,9 +328,11 @@ __global__ __launch_bounds__(DB_THREADS) void db_gather_k(const float* __restric
 // per chunk.  What moves through the LSD passes is the row itself, (x, y, z, original row) as one
 // float4: the cell key is a cheap function of (x, y, z) and is recomputed wherever a digit is
 // needed, so there is neither a key/index stream nor a random gather at the end (a 12-byte
-// gather costs a whole cache line).  Sweep H builds the digit histograms of every pass; pass 0
-// reads the input rows, the last pass writes the sorted rows and their full keys; a final sweep
-// flags the cell heads.  Replaces db_chunkbad, db_keys, every radix pass (histogram + 3 scan
+// gather costs a whole cache line).  Sweep B finds the chunk's own box in cell coordinates: what is
+// sorted is the key RELATIVE to it - same order, but as many bits as the chunk's extent needs (15-17 for a
+// 50 000-row chunk) instead of the tile's (21+), i.e. two 8/9-bit passes instead of three.  Sweep H builds
+// the digit histograms of every pass; pass 0 reads the input rows, the last pass writes the sorted rows and
+// their full keys; a final sweep flags the cell heads.  Replaces db_chunkbad, db_keys, every radix pass (histogram + 3 scan
 // kernels + scatter) and db_gather of the global path.
 struct Row3 { float x, y, z; };               // 4-byte aligned: loads as one global_load_dwordx3
 constexpr int CS_THREADS = 1024;
@@ -338,7 +340,8 @@ constexpr int CS_WAVES   = CS_THREADS / 64;
 constexpr int CS_ROUNDS  = 4;
 constexpr int CS_TILE    = CS_THREADS * CS_ROUNDS;
 constexpr int CS_PASSES  = 4;
-constexpr int CS_HREP    = 8;         // copies of every digit histogram (power of two)
+constexpr int CS_HREP    = 4;         // copies of every digit histogram (power of two)
+constexpr int CS_BINS    = 512;       // digits of up to 9 bits
 constexpr int64_t CS_MAX_CHUNK = 1 << 17;     // larger chunks use the global sort
 constexpr int64_t CS_MIN_CHUNKS = 96;         // fewer chunks: the global sort keeps more of the GPU busy
 
@@ -352,8 +355,7 @@ __device__ __forceinline__ uint32_t cs_cell_key(const DbGrid& g, float x, float 
 __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
     const float* __restrict__ xyz, int64_t n, DbGrid g, uint32_t* __restrict__ bad,
     float4* __restrict__ xbuf, float4* __restrict__ pts, uint64_t* __restrict__ keys_out,
-    uint32_t* __restrict__ head, uint32_t* __restrict__ status, int passes, int dbits,
-    unsigned long long* __restrict__ stamps) {
+    uint32_t* __restrict__ head, uint32_t* __restrict__ status, unsigned long long* __restrict__ stamps) {
 #ifdef PCH_CS_STAMPS                                    // phase timing of one workgroup (tuning builds only)
     int stamp_i = 0;
 #define CS_STAMP() if (stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) stamps[stamp_i++] = wall_clock64();
@@ -361,25 +363,72 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
 #define CS_STAMP()
 #endif
     CS_STAMP();
-    __shared__ uint32_t hist[CS_PASSES][CS_HREP][256];   // replicated: lanes of a wave that share a bin (most do: a
-                                                         // chunk covers few cells) spread over CS_HREP addresses
-    __shared__ uint32_t cnt[CS_WAVES][256];
-    __shared__ uint32_t off[CS_WAVES][256];
-    __shared__ uint32_t base[256];
-    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t hist[CS_PASSES][CS_HREP][CS_BINS];   // replicated: lanes of a wave that share a bin (most do: a
+                                                             // chunk covers few cells) spread over CS_HREP addresses
+    __shared__ uint32_t cnt[CS_WAVES][CS_BINS];
+    __shared__ uint32_t off[CS_WAVES][CS_BINS];
+    __shared__ uint32_t base[CS_BINS];
+    __shared__ uint32_t wsum[CS_BINS / 64];
     __shared__ uint32_t flags[2];                       // [0] chunk holds NaN/inf, [1] point outside the box
+    __shared__ uint32_t cbox[6];                        // the chunk's own box in cell coordinates: min xyz, max xyz
     const int tid = threadIdx.x, w = wave_id(), l = lane_id();
     const int64_t c = blockIdx.x;
     const int64_t lo = c * g.chunk_size;
     const int cn = (int)((n - lo) < g.chunk_size ? (n - lo) : g.chunk_size);
-    const uint32_t mask = (1u << dbits) - 1u;
     const Row3* __restrict__ rows = reinterpret_cast<const Row3*>(xyz) + lo;
-    for (int j = tid; j < CS_PASSES * CS_HREP * 256; j += CS_THREADS) (&hist[0][0][0])[j] = 0;
-    for (int j = tid; j < CS_WAVES * 256; j += CS_THREADS) (&cnt[0][0])[j] = 0;
+    for (int j = tid; j < CS_PASSES * CS_HREP * CS_BINS; j += CS_THREADS) (&hist[0][0][0])[j] = 0;
+    for (int j = tid; j < CS_WAVES * CS_BINS; j += CS_THREADS) (&cnt[0][0])[j] = 0;
     if (tid < 2) flags[tid] = 0;
+    if (tid < 6) cbox[tid] = tid < 3 ? 0xFFFFFFFFu : 0u;
     __syncthreads();
-    // ---- sweep H: digit histograms of every pass, NaN/inf and range checks
     constexpr int HU = 8;                               // rows per thread in flight
+    // ---- sweep B: NaN/inf and range checks, the chunk's box in cell coordinates
+    {
+        uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
+        for (int i0 = 0; i0 < cn; i0 += HU * CS_THREADS) {
+            Row3 q[HU];
+#pragma unroll
+            for (int u = 0; u < HU; ++u) {
+                const int i = i0 + u * CS_THREADS + tid;
+                q[u] = rows[i < cn ? i : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < HU; ++u) {
+                const bool in = i0 + u * CS_THREADS + tid < cn;
+                const bool fin = fabsf(q[u].x) < INFINITY && fabsf(q[u].y) < INFINITY && fabsf(q[u].z) < INFINITY;
+                uint32_t cc[3];
+                const bool ok = db_cell_coords(g, q[u].x, q[u].y, q[u].z, cc[0], cc[1], cc[2]);
+                if (in && !fin) flags[0] = 1u;
+                else if (in && !ok) flags[1] = 1u;
+                if (in && fin && ok) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { mn[a] = cc[a] < mn[a] ? cc[a] : mn[a]; mx[a] = cc[a] > mx[a] ? cc[a] : mx[a]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const uint32_t lo_w = wave_reduce_min(mn[a]), hi_w = wave_reduce_max(mx[a]);
+            if (l == 0) { atomicMin(&cbox[a], lo_w); atomicMax(&cbox[3 + a], hi_w); }
+        }
+    }
+    __syncthreads();
+    // widths of the relative key; rows outside the grid (the call fails for them) land on arbitrary digits
+    const uint32_t ox = cbox[0], oy = cbox[1], oz = cbox[2];
+    const bool any = cbox[3] >= ox && cbox[4] >= oy && cbox[5] >= oz;
+    const int wx = any && cbox[3] > ox ? 32 - __clz(cbox[3] - ox) : 0;
+    const int wy = any && cbox[4] > oy ? 32 - __clz(cbox[4] - oy) : 0;
+    const int wz = any && cbox[5] > oz ? 32 - __clz(cbox[5] - oz) : 0;
+    const int tb = wx + wy + wz;                         // <= bx + by + bz <= 32
+    const int passes = (tb + 8) / 9;
+    const int dbits = passes ? (tb + passes - 1) / passes : 1;
+    const uint32_t mask = (1u << dbits) - 1u;
+    const uint32_t gxm = (1u << g.bx) - 1u, gym = (1u << g.by) - 1u;
+    auto relkey = [&](uint32_t k) -> uint32_t {
+        const uint32_t cx = k & gxm, cy = (k >> g.bx) & gym, cz = k >> (g.bx + g.by);
+        return (uint32_t)((((((uint64_t)(cz - oz)) << wy) | (uint64_t)(cy - oy)) << wx) | (uint64_t)(cx - ox));   // tb <= 32
+    };
+    // ---- sweep H: digit histograms of every pass
     for (int i0 = 0; i0 < cn; i0 += HU * CS_THREADS) {  // workgroup-uniform trip count
         Row3 q[HU];
 #pragma unroll
@@ -390,11 +439,8 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
 #pragma unroll
         for (int u = 0; u < HU; ++u) {
             const bool in = i0 + u * CS_THREADS + tid < cn;
-            const bool fin = fabsf(q[u].x) < INFINITY && fabsf(q[u].y) < INFINITY && fabsf(q[u].z) < INFINITY;
             bool ok;
-            const uint32_t k = cs_cell_key(g, q[u].x, q[u].y, q[u].z, ok);
-            if (in && !fin) flags[0] = 1u;
-            else if (in && !ok) flags[1] = 1u;
+            const uint32_t k = relkey(cs_cell_key(g, q[u].x, q[u].y, q[u].z, ok));
             if (in)
                 for (int p = 0; p < passes; ++p) atomicAdd(&hist[p][l & (CS_HREP - 1)][(k >> (p * dbits)) & mask], 1u);
         }
@@ -408,13 +454,14 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
     }
     const int sh = g.bx + g.by + g.bz;
     const uint64_t hi = sh < 64 ? ((uint64_t)c << sh) : 0ull;
-    if (isbad || passes == 0) {                         // rows stay where they are, all in cell 0
+    if (isbad || passes == 0) {                         // rows stay where they are: one cell (cell 0 if bad)
         for (int i = tid; i < cn; i += CS_THREADS) {
             const Row3 q = rows[i];
             float4 o4;
             o4.x = q.x; o4.y = q.y; o4.z = q.z; o4.w = __uint_as_float((uint32_t)(lo + i));
             pts[lo + i] = o4;
-            keys_out[lo + i] = hi;
+            bool ok;
+            keys_out[lo + i] = isbad ? hi : (hi | cs_cell_key(g, q.x, q.y, q.z, ok));
             head[lo + i] = i == 0 ? 1u : 0u;
         }
         return;
@@ -428,7 +475,7 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
         float4* __restrict__ dst = ((passes - 1 - p) & 1) ? xbuf + lo : pts + lo;
         // exclusive scan of this pass' histogram
         uint32_t hv = 0, incl = 0;
-        if (tid < 256) {
+        if (tid < CS_BINS) {
             hv = 0;
 #pragma unroll
             for (int r = 0; r < CS_HREP; ++r) hv += hist[p][r][tid];
@@ -436,7 +483,7 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
             if (l == 63) wsum[w] = incl;
         }
         __syncthreads();
-        if (tid < 256) {
+        if (tid < CS_BINS) {
             uint32_t b = incl - hv;
             for (int w2 = 0; w2 < w; ++w2) b += wsum[w2];
             base[tid] = b;
@@ -471,10 +518,10 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
                 const bool valid = seg + r * 64 + l < cn;
                 bool ok;
                 key[r] = cs_cell_key(g, row[r].x, row[r].y, row[r].z, ok);
-                const uint32_t d = (key[r] >> shift) & mask;
+                const uint32_t d = (relkey(key[r]) >> shift) & mask;
                 uint64_t peers = __ballot(valid);
 #pragma unroll
-                for (int b = 0; b < 8; ++b) {
+                for (int b = 0; b < 9; ++b) {
                     const bool bit = (d >> b) & 1u;
                     const uint64_t m = __ballot(bit);
                     peers &= bit ? m : ~m;
@@ -487,7 +534,7 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
                 rank[r] = prior + rk;
             }
             __syncthreads();
-            if (tid < 256) {                            // digit tid: waves in order, counters cleared for the next tile
+            if (tid < CS_BINS) {                        // digit tid: waves in order, counters cleared for the next tile
                 uint32_t run = base[tid];
 #pragma unroll
                 for (int w2 = 0; w2 < CS_WAVES; ++w2) {
@@ -502,7 +549,7 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
 #pragma unroll
             for (int r = 0; r < CS_ROUNDS; ++r) {
                 if (seg + r * 64 + l < cn) {
-                    const uint32_t d = (key[r] >> shift) & mask;
+                    const uint32_t d = (relkey(key[r]) >> shift) & mask;
                     const uint32_t pos = off[w][d] + rank[r];
                     dst[pos] = row[r];
                     if (last) keys_out[lo + pos] = hi | key[r];
@@ -1705,16 +1752,13 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
         PCH_LAUNCH("db_gather", db_gather_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, ks, vs, n, w.pts, w.head);
     } else if (cellbits <= 32 && chunk_size <= CS_MAX_CHUNK && !force_global && (force_chunk || nchunks >= CS_MIN_CHUNKS)) {
         // chunk-local path: one workgroup per chunk builds keys, sorts and gathers
-        const int passes = cellbits <= 0 ? 0 : (cellbits + 7) / 8;
-        const int dbits = passes ? (cellbits + passes - 1) / passes : 1;
         PCH_LAUNCH("db_chunksort", db_chunksort_k, dim3((unsigned)nchunks), dim3(CS_THREADS), 0, s, xyz, n, g,
-                   w.chunk_bad, w.xbuf, w.pts, w.k1, w.head, w.meta + 6, passes, dbits,
-                   (unsigned long long*)w.cell_box);
+                   w.chunk_bad, w.xbuf, w.pts, w.k1, w.head, w.meta + 6, (unsigned long long*)w.cell_box);
 #ifdef PCH_CS_STAMPS
         {
             unsigned long long t[8];
             PCH_HIP_TRY(hipMemcpy(t, w.cell_box, sizeof(t), hipMemcpyDeviceToHost));
-            for (int q = 1; q <= passes + 2; ++q)
+            for (int q = 1; q <= 5; ++q)
                 fprintf(stderr, "chunksort phase %d: %.2f us\n", q, (double)(t[q] - t[q - 1]) / 100.0);
         }
 #endif
