@@ -121,52 +121,6 @@ __global__ __launch_bounds__(256) void sel_hist_k(const float* __restrict__ base
     }
 }
 
-// single workgroup: locate the bin holding the wanted rank, extend the prefix, clear hist
-template <int PASS>
-__global__ __launch_bounds__(256) void sel_pick_k(SelState* __restrict__ st, uint32_t* __restrict__ hist) {
-    __shared__ unsigned long long wsum[4];
-    __shared__ int found_bin;
-    __shared__ unsigned long long found_below;
-    const int nb = (PASS == 2) ? 256 : SEL_BINS;
-    const int per = nb / 256;                       // bins per thread (16 or 1)
-    const unsigned long long rank = st->rank;
-    unsigned long long loc[16];
-    unsigned long long tsum = 0;
-    for (int j = 0; j < per; ++j) { loc[j] = hist[threadIdx.x * per + j]; tsum += loc[j]; }
-    const unsigned long long incl = wave_scan_incl(tsum);
-    if (lane_id() == 63) wsum[wave_id()] = incl;
-    if (threadIdx.x == 0) found_bin = -1;
-    __syncthreads();
-    unsigned long long before = incl - tsum;
-    for (int w = 0; w < wave_id(); ++w) before += wsum[w];
-    // the thread whose bin range [before, before+tsum) contains rank owns the answer
-    if (rank >= before && rank < before + tsum) {
-        unsigned long long b = before;
-        for (int j = 0; j < per; ++j) {
-            if (rank < b + loc[j]) { found_bin = threadIdx.x * per + j; found_below = b; break; }
-            b += loc[j];
-        }
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < nb; j += 256) {
-        if (PASS == 2 && j == found_bin) {
-            // does rank+1 (the 'next' order statistic) still fall into this final bin?
-            const unsigned long long cnt = hist[j];
-            st->need_next = (rank + 1 < found_below + cnt) ? 0u : 1u;
-        }
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < nb; j += 256) hist[j] = 0;
-    if (threadIdx.x == 0) {
-        const int bin = found_bin < 0 ? 0 : found_bin;   // n == 0 never reaches here
-        st->less += found_below;
-        st->rank = rank - found_below;
-        if (PASS == 0) st->prefix = (uint32_t)bin;
-        else if (PASS == 1) st->prefix = (st->prefix << 12) | (uint32_t)bin;
-        else { st->v0key = (st->prefix << 8) | (uint32_t)bin; st->next_min = 0xFFFFFFFFu; }
-    }
-}
-
 // pass 4 (only when needed): smallest key strictly above v0key
 __global__ __launch_bounds__(256) void sel_next_k(const float* __restrict__ base_in, int64_t n,
                                                   int64_t stride, SelState* __restrict__ st,
@@ -205,21 +159,194 @@ __device__ __forceinline__ float sel_key_to_float(uint32_t k) {
     return (k == 0xFFFFFFFFu) ? __uint_as_float(0x7FC00000u) : f32_unordered(k);
 }
 
-// numpy _lerp in float32: a + (b-a)*t, and b - (b-a)*(1-t) where t >= 0.5
-// (numpy/lib/_function_base_impl.py:4639-4660); NaN anywhere -> NaN.
-// scal: [0] = percentile, [1] = percentile + add1, [2] = percentile + add2
-__global__ void sel_lerp_k(const SelState* __restrict__ st, int same_index, float gamma,
-                           const float* __restrict__ sub, float add1, float add2,
-                           float* __restrict__ scal) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// (the interpolation itself is numpy's _lerp in float32: a + (b-a)*t, and b - (b-a)*(1-t) where t >= 0.5,
+// numpy/lib/_function_base_impl.py:4639-4660; NaN anywhere -> NaN.  scal: [0] = percentile,
+// [1] = percentile + add1, [2] = percentile + add2 - see selx_lerp_k)
+
+// ---- the same select with every pick folded into its consumer --------------------------------------
+// A kernel of a few microseconds still costs a launch slot (~5 us each on this stream), and a percentile used
+// to be 9 of them (27 with the sample bracket below).  Here the single-workgroup pick of pass p runs as the
+// prologue of whatever needs its result - histogram pass p+1, the "next key" pass, the bracket sweep, the final
+// interpolation: every workgroup repeats it from the finished histogram of pass p (16 KB, L2), workgroup 0 stores
+// the new state for the kernels behind.  Histograms of the three passes live side by side and are cleared once.
+// NR = 2 selects two ranks of the same data in the same sweeps (the two ends of the sample bracket).
+struct SelRun {
+    SelState st[4];                 // st[p]: state in front of histogram pass p; st[3]: after the last pick
+    unsigned long long nan_count;
+    uint32_t next_min, pad;
+};
+__device__ __forceinline__ uint32_t* selx_hist_of(uint32_t* hist, int run, int pass) {
+    return hist + ((pass == 0 ? 0 : run) * 3 + pass) * SEL_BINS;        // pass 0 has no prefix: one histogram for all runs
+}
+
+template <int PASS>
+__device__ __forceinline__ SelState sel_pick_block(const SelState& in, const uint32_t* __restrict__ hist) {
+    __shared__ unsigned long long wsum[4];
+    __shared__ int found_bin;
+    __shared__ unsigned long long found_below, found_cnt;
+    constexpr int nb = (PASS == 2) ? 256 : SEL_BINS;
+    constexpr int per = nb / 256;                   // bins per thread (16 or 1)
+    const unsigned long long rank = in.rank;
+    unsigned long long loc[per];
+    unsigned long long tsum = 0;
+#pragma unroll
+    for (int j = 0; j < per; ++j) { loc[j] = hist[threadIdx.x * per + j]; tsum += loc[j]; }
+    const unsigned long long incl = wave_scan_incl(tsum);
+    __syncthreads();                                // a previous call may still be reading the shared words
+    if (lane_id() == 63) wsum[wave_id()] = incl;
+    if (threadIdx.x == 0) found_bin = -1;
+    __syncthreads();
+    unsigned long long before = incl - tsum;
+    for (int w = 0; w < wave_id(); ++w) before += wsum[w];
+    if (rank >= before && rank < before + tsum) {   // the thread whose bins hold the rank
+        unsigned long long b = before;
+#pragma unroll
+        for (int j = 0; j < per; ++j) {
+            if (rank >= b && rank < b + loc[j]) { found_bin = threadIdx.x * per + j; found_below = b; found_cnt = loc[j]; }
+            b += loc[j];
+        }
+    }
+    __syncthreads();
+    SelState out = in;
+    const bool hit = found_bin >= 0;                // (an empty input never gets here)
+    const uint32_t bin = hit ? (uint32_t)found_bin : 0u;
+    const unsigned long long below = hit ? found_below : 0ull;
+    out.less = in.less + below;
+    out.rank = rank - below;
+    if (PASS == 0) out.prefix = bin;
+    else if (PASS == 1) out.prefix = (in.prefix << 12) | bin;
+    else {
+        out.v0key = (in.prefix << 8) | bin;
+        out.need_next = (hit && rank + 1 < found_below + found_cnt) ? 0u : 1u;   // is rank+1 in this final bin too?
+    }
+    return out;
+}
+
+template <int PASS, int NR>
+__global__ __launch_bounds__(256) void selx_hist_k(const float* __restrict__ base_in, int64_t n, int64_t stride,
+                                                   SelRun* __restrict__ run, uint32_t* __restrict__ hist,
+                                                   SelGate gate) {
+    const float* base = base_in;
+    sel_gate(gate, base, n, stride);
+    constexpr int REP = PASS == 0 ? SEL_REP0 : 1;
+    constexpr int NH = PASS == 0 ? 1 : NR;
+    __shared__ uint32_t hh[NH][REP][SEL_BINS];
+    uint32_t prefix[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        prefix[r] = 0;
+        if (PASS >= 1) {
+            const SelState st = sel_pick_block<(PASS >= 1 ? PASS - 1 : 0)>(run[r].st[PASS >= 1 ? PASS - 1 : 0],
+                                                                             selx_hist_of(hist, r, PASS >= 1 ? PASS - 1 : 0));
+            if (blockIdx.x == 0 && threadIdx.x == 0) run[r].st[PASS] = st;
+            prefix[r] = st.prefix;
+        }
+    }
+    for (int j = threadIdx.x; j < NH * REP * SEL_BINS; j += 256) (&hh[0][0][0])[j] = 0;
+    __syncthreads();
+    const int rep = lane_id() & (REP - 1);
+    unsigned long long nans = 0;
+    auto take = [&](bool in, float v) {
+        const uint32_t k = sel_key(v);
+        if (PASS == 0) {
+            if (in) atomicAdd(&hh[0][rep][k >> 20], 1u);
+            nans += (in && v != v);
+        } else {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                if (PASS == 1) sel_hist_add<1>(hh[r < NH ? r : 0][0], in && (k >> 20) == prefix[r], (k >> 8) & 0xFFFu);
+                else sel_hist_add<1>(hh[r < NH ? r : 0][0], in && (k >> 8) == prefix[r], k & 0xFFu);
+            }
+        }
+    };
+    const int64_t span = (int64_t)gridDim.x * SEL_TILE;
+    const bool vec = stride == 1 && (reinterpret_cast<uintptr_t>(base) & 15u) == 0;
+    for (int64_t t0 = (int64_t)blockIdx.x * SEL_TILE; t0 < n; t0 += span) {    // wave-uniform trip count
+        if (vec && t0 + SEL_TILE <= n) {
+            const float4* b4 = reinterpret_cast<const float4*>(base + t0);
+            float4 q[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q[r] = b4[r * 256 + threadIdx.x];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { take(true, q[r].x); take(true, q[r].y); take(true, q[r].z); take(true, q[r].w); }
+        } else {
+#pragma unroll 4
+            for (int r = 0; r < SEL_TILE / 256; ++r) {
+                const int64_t i = t0 + r * 256 + threadIdx.x;
+                const bool in = i < n;
+                take(in, in ? base[i * stride] : 0.0f);
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int nb = (PASS == 2) ? 256 : SEL_BINS;
+#pragma unroll
+    for (int r = 0; r < NH; ++r) {
+        uint32_t* out = selx_hist_of(hist, r, PASS);
+        for (int j = threadIdx.x; j < nb; j += 256) {
+            uint32_t t = 0;
+#pragma unroll
+            for (int c = 0; c < REP; ++c) t += hh[r][c][j];
+            if (t) atomicAdd(&out[j], t);
+        }
+    }
+    if (PASS == 0) {
+        nans = wave_reduce_add(nans);
+        if (lane_id() == 0 && nans) atomicAdd(&run[0].nan_count, nans);
+    }
+}
+
+// smallest key strictly above the selected one (only when rank+1 lies beyond its final bin); the last pick first
+__global__ __launch_bounds__(256) void selx_next_k(const float* __restrict__ base_in, int64_t n, int64_t stride,
+                                                   SelRun* __restrict__ run, uint32_t* __restrict__ hist, SelGate gate) {
+    const float* base = base_in;
+    sel_gate(gate, base, n, stride);
+    const SelState st = sel_pick_block<2>(run->st[2], selx_hist_of(hist, 0, 2));
+    if (blockIdx.x == 0 && threadIdx.x == 0) run->st[3] = st;
+    if (st.need_next == 0) return;
+    const uint32_t v0 = st.v0key;
+    uint32_t best = 0xFFFFFFFFu;
+    auto take = [&](float v) {
+        const uint32_t k = sel_key(v);
+        if (k > v0 && k < best) best = k;
+    };
+    const int64_t span = (int64_t)gridDim.x * SEL_TILE;
+    const bool vec = stride == 1 && (reinterpret_cast<uintptr_t>(base) & 15u) == 0;
+    for (int64_t t0 = (int64_t)blockIdx.x * SEL_TILE; t0 < n; t0 += span) {
+        if (vec && t0 + SEL_TILE <= n) {
+            const float4* b4 = reinterpret_cast<const float4*>(base + t0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 q = b4[r * 256 + threadIdx.x];
+                take(q.x); take(q.y); take(q.z); take(q.w);
+            }
+        } else {
+            for (int r = 0; r < SEL_TILE / 256; ++r) {
+                const int64_t i = t0 + r * 256 + threadIdx.x;
+                if (i < n) take(base[i * stride]);
+            }
+        }
+    }
+    best = wave_reduce_min(best);
+    if (lane_id() == 0 && best != 0xFFFFFFFFu) atomicMin(&run->next_min, best);
+}
+
+// the final interpolation; picked = 0: the last pick has not run yet (there was no "next" pass)
+__global__ __launch_bounds__(256) void selx_lerp_k(const SelRun* __restrict__ run, const uint32_t* __restrict__ hist2,
+                                                   int picked, int same_index, float gamma,
+                                                   const float* __restrict__ sub, float add1, float add2,
+                                                   float* __restrict__ scal) {
+    SelState st = run->st[3];
+    if (!picked) st = sel_pick_block<2>(run->st[2], hist2);
+    if (threadIdx.x != 0) return;
     const float c = sub ? *sub : 0.0f;
-    const float a = sel_key_to_float(st->v0key) - c;
+    const float a = sel_key_to_float(st.v0key) - c;
     float b = a;
-    if (!same_index && st->need_next) b = sel_key_to_float(st->next_min) - c;
+    if (!same_index && st.need_next) b = sel_key_to_float(run->next_min) - c;
     const float diff = b - a;
     float r = a + diff * gamma;
     if (gamma >= 0.5f) r = b - diff * (1.0f - gamma);
-    if (st->nan_count) r = __uint_as_float(0x7FC00000u);
+    if (run->nan_count) r = __uint_as_float(0x7FC00000u);
     scal[0] = r;
     scal[1] = r + add1;
     scal[2] = r + add2;
@@ -253,13 +380,17 @@ __global__ void sel_sample_k(const float* __restrict__ base, int64_t ns, float* 
 constexpr int SEL_STAGE = 2 * SEL_TILE;                  // candidates a workgroup stages in LDS before it reserves output
 
 __global__ __launch_bounds__(256) void sel_bracket_k(const float* __restrict__ base, int64_t n,
-                                                     const SelState* __restrict__ lo, const SelState* __restrict__ hi,
+                                                     const SelRun* __restrict__ lohi, uint32_t* __restrict__ hist,
+                                                     int lo_is_min, int hi_is_max,
                                                      BrState* __restrict__ br, float* __restrict__ cand, uint32_t cap) {
     // candidates are staged in LDS and written out a few thousand at a time: one global atomic per flush (a
     // reservation per wave would be ~1.5 M atomics on one address for 100 M values - 13 ms, measured)
     __shared__ float stage[SEL_STAGE];
     __shared__ uint32_t nstage, gbase;
-    const uint32_t L = lo->v0key, H = hi->v0key;
+    // the last picks of the two sample selects; a bracket that reaches the bottom / top of the sample is open there
+    const uint32_t Lk = sel_pick_block<2>(lohi[0].st[2], selx_hist_of(hist, 0, 2)).v0key;
+    const uint32_t Hk = sel_pick_block<2>(lohi[1].st[2], selx_hist_of(hist, 1, 2)).v0key;
+    const uint32_t L = lo_is_min ? 0u : Lk, H = hi_is_max ? 0xFFFFFFFFu : Hk;
     unsigned long long less = 0, nans = 0;
     const uint64_t lt = lanemask_lt();
     if (threadIdx.x == 0) nstage = 0;
@@ -321,7 +452,7 @@ __global__ __launch_bounds__(256) void sel_bracket_k(const float* __restrict__ b
 }
 
 // decides whether the candidates hold both order statistics and prepares the state of whichever select runs next
-__global__ void sel_bracket_fix_k(BrState* __restrict__ br, SelState* __restrict__ st, unsigned long long k0, int same) {
+__global__ void sel_bracket_fix_k(BrState* __restrict__ br, SelRun* __restrict__ run, unsigned long long k0, int same) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const unsigned long long less = br->less, cnt = br->count;
     const bool ok = br->overflow == 0 && less <= k0 && (k0 - less) < cnt && (same || (k0 + 1 - less) < cnt);
@@ -329,9 +460,25 @@ __global__ void sel_bracket_fix_k(BrState* __restrict__ br, SelState* __restrict
     SelState z;
     z.rank = ok ? k0 - less : k0;
     z.less = 0; z.prefix = 0; z.need_next = 0; z.v0key = 0; z.v1key = 0;
-    z.nan_count = ok ? br->nan : 0ull;                     // (the full passes count NaN themselves)
-    z.next_min = 0; z.pad = 0;
-    *st = z;
+    z.nan_count = 0; z.next_min = 0; z.pad = 0;
+    run->st[0] = z;
+    run->nan_count = ok ? br->nan : 0ull;                  // (the full passes count NaN themselves)
+}
+
+// one launch in front of a select: clears the histograms (and the bracket state), sets the ranks of up to 3 runs
+__global__ __launch_bounds__(256) void selx_init_k(uint32_t* __restrict__ hist, int nwords, SelRun* __restrict__ runs,
+                                                   int nruns, unsigned long long r0, unsigned long long r1,
+                                                   unsigned long long r2, BrState* __restrict__ br) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nwords) hist[i] = 0;
+    if (i < nruns) {
+        SelRun z;
+        memset(&z, 0, sizeof(z));
+        z.st[0].rank = i == 0 ? r0 : (i == 1 ? r1 : r2);
+        z.next_min = 0xFFFFFFFFu;
+        runs[i] = z;
+    }
+    if (i == 0 && br) { BrState b; memset(&b, 0, sizeof(b)); *br = b; }
 }
 
 struct SelWs {
@@ -339,7 +486,8 @@ struct SelWs {
     uint32_t* hist;
     float*    scal;     // 4 floats
     // bracketed select (n >= SEL_BRACKET_MIN)
-    SelState *st_lo, *st_hi;
+    SelRun*   run;      // [0], [1]: the two ends of the sample bracket, [2]: the select proper
+    uint32_t* xhist;    // [3 runs][3 passes][SEL_BINS]
     BrState*  br;
     float    *sample, *cand;
     int64_t   ns;       // sample size
@@ -349,10 +497,10 @@ static void sel_plan(Arena& a, SelWs& w, int64_t n = 0) {
     w.st = a.take<SelState>(1);
     w.hist = a.take<uint32_t>(SEL_BINS);
     w.scal = a.take<float>(4);
-    w.st_lo = w.st_hi = nullptr; w.br = nullptr; w.sample = w.cand = nullptr; w.ns = 0; w.cap = 0;
+    w.run = a.take<SelRun>(3);
+    w.xhist = a.take<uint32_t>(9 * SEL_BINS);
+    w.br = nullptr; w.sample = w.cand = nullptr; w.ns = 0; w.cap = 0;
     if (n >= SEL_BRACKET_MIN) {
-        w.st_lo = a.take<SelState>(1);
-        w.st_hi = a.take<SelState>(1);
         w.br = a.take<BrState>(1);
         w.ns = SEL_GROUP * (n / SEL_EVERY);
         w.sample = a.take<float>(w.ns);
@@ -380,39 +528,31 @@ static PctIndex pct_index(int64_t n, double q_percent) {
     return r;
 }
 
-// three histogram / pick rounds (+ the "next key" pass) on `st` / `hist`; st and hist are prepared by the caller
-static int select_rounds(const float* base, int64_t n, int64_t stride, bool with_next, SelState* st, uint32_t* hist,
+// three histogram passes (+ the "next key" pass) on one SelRun; run and histograms are prepared by the caller
+static int select_rounds(const float* base, int64_t n, int64_t stride, bool with_next, SelRun* run, uint32_t* hist,
                          hipStream_t s, SelGate gate, int64_t grid_n) {
     int64_t gb = ceil_div(grid_n, SEL_TILE);
     if (gb > 2048) gb = 2048;
     if (gb < 1) gb = 1;
     const dim3 grid((unsigned)gb), blk(256);
-    PCH_LAUNCH("sel_hist0", sel_hist_k<0>, grid, blk, 0, s, base, n, stride, st, hist, gate);
-    PCH_LAUNCH("sel_pick0", sel_pick_k<0>, dim3(1), blk, 0, s, st, hist);
-    PCH_LAUNCH("sel_hist1", sel_hist_k<1>, grid, blk, 0, s, base, n, stride, st, hist, gate);
-    PCH_LAUNCH("sel_pick1", sel_pick_k<1>, dim3(1), blk, 0, s, st, hist);
-    PCH_LAUNCH("sel_hist2", sel_hist_k<2>, grid, blk, 0, s, base, n, stride, st, hist, gate);
-    PCH_LAUNCH("sel_pick2", sel_pick_k<2>, dim3(1), blk, 0, s, st, hist);
-    if (with_next) PCH_LAUNCH("sel_next", sel_next_k, grid, blk, 0, s, base, n, stride, st, gate);
+    PCH_LAUNCH("sel_hist0", (selx_hist_k<0, 1>), grid, blk, 0, s, base, n, stride, run, hist, gate);
+    PCH_LAUNCH("sel_hist1", (selx_hist_k<1, 1>), grid, blk, 0, s, base, n, stride, run, hist, gate);
+    PCH_LAUNCH("sel_hist2", (selx_hist_k<2, 1>), grid, blk, 0, s, base, n, stride, run, hist, gate);
+    if (with_next) PCH_LAUNCH("sel_next", selx_next_k, grid, blk, 0, s, base, n, stride, run, hist, gate);
     return PCH_OK;
 }
 
-__global__ void sel_init_k(SelState* st, unsigned long long rank) {
-    SelState z;
-    z.rank = rank; z.less = 0; z.prefix = 0; z.need_next = 0; z.v0key = 0; z.v1key = 0; z.nan_count = 0;
-    z.next_min = 0; z.pad = 0;
-    *st = z;
-}
-
-// the histogram / pick / next passes (need only the raw values) ...
+// the histogram / next passes (need only the raw values) ...
 static int select_passes(const float* base, int64_t n, int64_t stride, double q_percent, SelWs& w,
                          hipStream_t s) {
     const PctIndex pi = pct_index(n, q_percent);
     const SelGate always = {nullptr, nullptr, nullptr};
-    PCH_HIP_TRY(hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * SEL_BINS, s));
+    SelRun* fin = w.run + 2;
+    uint32_t* hfin = w.xhist + 6 * SEL_BINS;
     if (!(w.sample && stride == 1 && n >= SEL_BRACKET_MIN)) {
-        PCH_LAUNCH("sel_init", sel_init_k, dim3(1), dim3(1), 0, s, w.st, (unsigned long long)pi.k0);
-        return select_rounds(base, n, stride, !pi.same, w.st, w.hist, s, always, n);
+        PCH_LAUNCH("sel_init", selx_init_k, dim3((unsigned)ceil_div(9 * SEL_BINS, 256)), dim3(256), 0, s, w.xhist,
+                   9 * SEL_BINS, w.run, 3, 0ull, 0ull, (unsigned long long)pi.k0, (BrState*)nullptr);
+        return select_rounds(base, n, stride, !pi.same, fin, hfin, s, always, n);
     }
     // ---- bracket from the sample: ranks around k0 * ns / n, six sigma for ns/16 independent draws + 0.2 %
     const int64_t ns = w.ns;
@@ -422,35 +562,35 @@ static int select_passes(const float* base, int64_t n, int64_t stride, double q_
     const int64_t mid = (int64_t)(p * (double)(ns - 1));
     const int64_t r_lo = mid - margin < 0 ? 0 : mid - margin;
     const int64_t r_hi = mid + margin > ns - 1 ? ns - 1 : mid + margin;
+    PCH_LAUNCH("sel_init", selx_init_k, dim3((unsigned)ceil_div(9 * SEL_BINS, 256)), dim3(256), 0, s, w.xhist,
+               9 * SEL_BINS, w.run, 3, (unsigned long long)r_lo, (unsigned long long)r_hi, 0ull, w.br);
     PCH_LAUNCH("sel_sample", sel_sample_k, dim3((unsigned)ceil_div(ns, 256)), dim3(256), 0, s, base, ns, w.sample);
-    SelState* sts[2] = {w.st_lo, w.st_hi};
-    const int64_t rk[2] = {r_lo, r_hi};
-    for (int k = 0; k < 2; ++k) {
-        PCH_LAUNCH("sel_init", sel_init_k, dim3(1), dim3(1), 0, s, sts[k], (unsigned long long)rk[k]);
-        PCH_TRY(select_rounds(w.sample, ns, 1, false, sts[k], w.hist, s, always, ns));      // (each pick clears hist)
+    {                                                      // both ends of the bracket in the same three sweeps
+        int64_t gs = ceil_div(ns, SEL_TILE);
+        if (gs > 2048) gs = 2048;
+        if (gs < 1) gs = 1;
+        const dim3 grid((unsigned)gs), blk(256);
+        PCH_LAUNCH("sel_hist0", (selx_hist_k<0, 2>), grid, blk, 0, s, (const float*)w.sample, ns, (int64_t)1, w.run, w.xhist, always);
+        PCH_LAUNCH("sel_hist1", (selx_hist_k<1, 2>), grid, blk, 0, s, (const float*)w.sample, ns, (int64_t)1, w.run, w.xhist, always);
+        PCH_LAUNCH("sel_hist2", (selx_hist_k<2, 2>), grid, blk, 0, s, (const float*)w.sample, ns, (int64_t)1, w.run, w.xhist, always);
     }
-    if (r_lo == 0)                                         // the bracket reaches the bottom: everything counts from key 0
-        PCH_HIP_TRY(hipMemsetAsync(&w.st_lo->v0key, 0, sizeof(uint32_t), s));
-    if (r_hi == ns - 1)                                    // ... or the top
-        PCH_HIP_TRY(hipMemsetAsync(&w.st_hi->v0key, 0xFF, sizeof(uint32_t), s));
-    PCH_HIP_TRY(hipMemsetAsync(w.br, 0, sizeof(BrState), s));
     int64_t gb = ceil_div(n, SEL_TILE);
     if (gb > 2048) gb = 2048;
-    PCH_LAUNCH("sel_bracket", sel_bracket_k, dim3((unsigned)gb), dim3(256), 0, s, base, n, (const SelState*)w.st_lo,
-               (const SelState*)w.st_hi, w.br, w.cand, w.cap);
-    PCH_LAUNCH("sel_bracket_fix", sel_bracket_fix_k, dim3(1), dim3(64), 0, s, w.br, w.st, (unsigned long long)pi.k0,
+    PCH_LAUNCH("sel_bracket", sel_bracket_k, dim3((unsigned)gb), dim3(256), 0, s, base, n, (const SelRun*)w.run, w.xhist,
+               r_lo == 0 ? 1 : 0, r_hi == ns - 1 ? 1 : 0, w.br, w.cand, w.cap);
+    PCH_LAUNCH("sel_bracket_fix", sel_bracket_fix_k, dim3(1), dim3(64), 0, s, w.br, fin, (unsigned long long)pi.k0,
                pi.same);
     // exact select: on the candidates when the bracket holds, else over the whole column - the same launches either
     // way, the kernels pick their source from br->ok
     const SelGate src = {&w.br->ok, w.cand, &w.br->count};
-    return select_rounds(base, n, stride, !pi.same, w.st, w.hist, s, src, n);
+    return select_rounds(base, n, stride, !pi.same, fin, hfin, s, src, n);
 }
 // ... and the final interpolation, which is where `sub` (the centroid) enters
 static int select_lerp(int64_t n, const float* sub, double q_percent, float add1, float add2, SelWs& w,
                        hipStream_t s) {
     const PctIndex pi = pct_index(n, q_percent);
-    PCH_LAUNCH("sel_lerp", sel_lerp_k, dim3(1), dim3(64), 0, s, (const SelState*)w.st, pi.same, pi.gamma,
-               sub, add1, add2, w.scal);
+    PCH_LAUNCH("sel_lerp", selx_lerp_k, dim3(1), dim3(256), 0, s, (const SelRun*)(w.run + 2),
+               (const uint32_t*)(w.xhist + 8 * SEL_BINS), pi.same ? 0 : 1, pi.same, pi.gamma, sub, add1, add2, w.scal);
     return PCH_OK;
 }
 static int select_percentile(const float* base, int64_t n, int64_t stride, const float* sub,
