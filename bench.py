@@ -85,9 +85,9 @@ def algorithmic_bytes(name, N, NF):
     table = {
         "mean_summary": 16 * N, "sel_hist0": 4 * N, "sel_hist1": 4 * N, "sel_hist2": 4 * N,
         "sel_next": 4 * N, "gf_compact": 4 * N + 8 * NF + 16 * NF,    # z column, x/y of survivors, rows + index out
-        # chunk sort: rows in (12) twice (histogram sweep, pass 0), 16-byte rows through the passes,
-        # rows + 8-byte keys out, head flags: 124 B per point at 3 passes
-        "db_chunksort": 124 * NF,
+        # chunk sort: rows in (12) three times (box sweep, histogram sweep, pass 0), 16-byte rows through the
+        # passes, rows + 8-byte keys out, head flags: 100 B per point at 2 passes (keys relative to the chunk's box)
+        "db_chunksort": 100 * NF,
         "db_keys": 24 * NF, "db_gather": 44 * NF, "db_cells": 24 * NF, "db_label": 33 * NF,
         "radix_hist": 8 * NF, "radix_scatter": 24 * NF, "scan_reduce": 4 * NF, "scan_apply": 8 * NF,
         "seg_keys": 16 * NF, "seg_perm": 8 * NF, "seg_stats": 16 * NF, "seg_hist": 4 * NF, "seg_scatter": 8 * NF,
