@@ -1,6 +1,7 @@
 """Idle gaps of one step from a rocprofv3 kernel trace (csv with Start_Timestamp / End_Timestamp).
-python tools/timeline.py <kernel_trace.csv> [steps]   - prints the kernels of the last step in launch order with
-the gap in front of each, and the busy / idle split (union over streams)."""
+python tools/timeline.py <kernel_trace.csv> [marker]   - prints the kernels of the last step in launch order with
+the gap in front of each, and the busy / idle split (union over streams).  A step starts at every launch of the
+marker kernel (default ms_summary_k; vx_minmax_k for the voxel stage)."""
 import csv
 import sys
 
@@ -8,7 +9,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].split("(")[0].replace("pch::", "").replace("void ", "")[:28]
 # a step starts at every ms_summary_k launch
-starts = [i for i, r in enumerate(rows) if "ms_summary_k" in r["Kernel_Name"]]
+marker = sys.argv[2] if len(sys.argv) > 2 else "ms_summary_k"
+starts = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
 if len(starts) < 3:
     sys.exit("fewer than 3 steps in the trace")
 a, b = starts[-2], starts[-1]
