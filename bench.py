@@ -316,8 +316,8 @@ def main():
                     "centre_delta_m": {"median": dc[len(dc) // 2] if dc else None, "max": dc[-1] if dc else None,
                                        "above_1e-3": sum(d > 1e-3 for d in dc)},
                     "extent_delta_m": {"median": de[len(de) // 2] if de else None, "max": de[-1] if de else None},
-                    "note": "opt-in (PCH_OBB_MODE=fast): pch_obb_shell_f32 + qhull on the kept ~1 % + "
-                            "pch_obb_min_boxes_f64; exact mode stays the default"}
+                    "note": "opt-in (PCH_OBB_MODE=fast): pch_obb_shell_f32 + qhull on the kept ~1 % (in the worker "
+                            "processes the exact mode started) + pch_obb_min_boxes_f64; exact mode stays the default"}
             except Exception as e:
                 out["tower_table_fast"] = {"error": str(e)}
         except Exception as e:

@@ -157,6 +157,16 @@ def bounding_box_oriented(points, extent_order="unsorted"):
     return extents, np.linalg.inv(to_origin)
 
 
+def _hull_triangles(points):
+    """(hull vertices [nv,3] in ascending input order, triangles [nt,3] int32 into them, qhull's order)."""
+    p = np.asarray(points, dtype=np.float64)
+    hull = ConvexHull(p, qhull_options="QbB Pp Qt")
+    ids = np.sort(hull.vertices)
+    remap = np.empty(len(p), dtype=np.int32)
+    remap[ids] = np.arange(len(ids), dtype=np.int32)
+    return p[ids], remap[hull.simplices]
+
+
 # ---- many clusters at once -------------------------------------------------------------
 # The boxes of different clusters are independent, and qhull + the direction search hold the
 # GIL, so threads do not help.  PCH_OBB_WORKERS > 1 spreads the clusters over worker PROCESSES:
@@ -172,6 +182,8 @@ def _boxed(args):
     try:
         if extent_order == "__hull__":        # first half only: the native search runs in the caller
             return hull_candidates(points), None
+        if extent_order == "__hulltri__":     # fast mode: hull vertices + qhull's triangles for pch_obb_min_boxes_f64
+            return _hull_triangles(points), None
         return bounding_box_oriented(points, extent_order), None
     except Exception as e:                    # reported per cluster, like the serial loop does
         return None, e
@@ -311,9 +323,10 @@ def _per_cluster(clusters, what, workers):
 # all clusters at once (pch_obb_min_boxes_f64).  Extents and centres agree with the exact mode to rounding
 # whenever qhull builds the same facets from the reduced input - mostly, not always,
 # and the sign of the two rectangle axes follows our own edge orientation, not qhull's.  Opt-in.
-def boxes_fast(points, perm, offsets, nclusters, extent_order="unsorted", nthreads=0):
+def boxes_fast(points, perm, offsets, nclusters, extent_order="unsorted", nthreads=0, workers=None):
     """points float32 [N_f,3] (device), perm / offsets as returned by ops.segment_by_label.
-    Returns a list of ((extents, transform), None) or (None, exception) per cluster, in label order."""
+    Returns a list of ((extents, transform), None) or (None, exception) per cluster, in label order.
+    workers: processes for the qhull calls on the kept points; None: those that are already running (prestart)."""
     import torch
     from . import ops
     if extent_order not in _EXTENT_ORDERS:
@@ -329,20 +342,17 @@ def boxes_fast(points, perm, offsets, nclusters, extent_order="unsorted", nthrea
     verts, tris, vo, to = [], [], [0], [0]
     results = [None] * K
     hulls = []
-    for k in range(K):
-        p = kept[bounds[k]:bounds[k + 1]]
-        try:
-            hull = ConvexHull(p, qhull_options="QbB Pp Qt")
-        except Exception as e:                                   # QhullError: too few / degenerate points
+    parts = [kept[bounds[k]:bounds[k + 1]] for k in range(K)]
+    if workers is None:                       # worker processes that are already running take the hulls (qhull holds the GIL)
+        workers = len(_WORKERS) if K >= 16 else 1
+    for k, (h, e) in enumerate(_per_cluster(parts, "__hulltri__", workers)):
+        if e is not None:                     # QhullError: too few / degenerate points
             results[k] = (None, e)
             continue
-        ids = np.sort(hull.vertices)
-        remap = np.empty(len(p), dtype=np.int32)
-        remap[ids] = np.arange(len(ids), dtype=np.int32)
-        verts.append(p[ids])
-        tris.append(remap[hull.simplices])
-        vo.append(vo[-1] + len(ids))
-        to.append(to[-1] + len(hull.simplices))
+        verts.append(h[0])
+        tris.append(h[1])
+        vo.append(vo[-1] + len(h[0]))
+        to.append(to[-1] + len(h[1]))
         hulls.append(k)
     if hulls:
         T, E, S = ops.obb_min_boxes(np.concatenate(verts), vo, np.concatenate(tris), to,

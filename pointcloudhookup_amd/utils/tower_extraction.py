@@ -68,7 +68,7 @@ def extract_towers(
         import torch
         from .. import las as _las
         from .. import ops, pipeline
-        if OBB_MODE == "exact" and os.path.getsize(input_las_path) >= PRESTART_BYTES:
+        if os.path.getsize(input_las_path) >= PRESTART_BYTES:
             from .. import obb as _obb
             _obb.prestart()                # the box workers import scipy while the file is being read
         dev = torch.device(DEVICE)
