@@ -53,6 +53,9 @@ def tiles_of_rank(n_tiles, rank, world):
     return list(range(start, start + per + (1 if rank < extra else 0)))
 
 
+RECONCILE_CAP = 1024          # clusters per rank that travel in the first (usually only) exchange
+
+
 def reconcile(nclusters, table, group=None):
     """Makes per-rank cluster ids global.
 
@@ -71,15 +74,45 @@ def reconcile(nclusters, table, group=None):
     if dist.get_backend(group) == "gloo" and table.is_cuda:     # gloo rehearsal: exchange on the host
         table = table.cpu()
     dev = table.device
-    cnt = torch.tensor([int(nclusters)], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(counts, cnt, group=group)
-    counts = [int(c.item()) for c in counts]
-    kmax = max(max(counts), 1)
+    k = int(nclusters)
     C = table.shape[1] if table.dim() == 2 else 1
+    # ONE collective and ONE host read in the usual case: every rank sends a fixed-capacity block whose first row
+    # carries its cluster count (a step of the tile stream is ~2.4 ms; two collectives with a host read per rank
+    # between them cost a tenth of that).  Only if some rank holds more clusters than the block does a second,
+    # exactly sized exchange follow - every rank sees the same counts, so all take the same branch.
+    cap = RECONCILE_CAP
+    if not table.dtype.is_floating_point or k >= 2 ** 24:
+        cap = 0                                                 # the count must survive the table's dtype exactly
+    counts = None
+    if cap:
+        block = torch.zeros((cap + 1, C), dtype=table.dtype, device=dev)
+        block[0, 0] = k
+        m = min(k, cap)
+        if m:
+            block[1:1 + m] = table[:m].reshape(m, C)
+        out = torch.empty((world * (cap + 1), C), dtype=table.dtype, device=dev)
+        try:
+            dist.all_gather_into_tensor(out, block, group=group)
+        except (RuntimeError, AttributeError, NotImplementedError):     # a backend without the flat form
+            parts = [torch.empty_like(block) for _ in range(world)]
+            dist.all_gather(parts, block, group=group)
+            out = torch.cat(parts, dim=0)
+        out = out.reshape(world, cap + 1, C)
+        counts = [int(v) for v in out[:, 0, 0].to(torch.float64).tolist()]
+        if max(counts) <= cap:
+            parts = [out[r, 1:1 + c] for r, c in enumerate(counts)]
+            owner = torch.cat([torch.full((c,), r, dtype=torch.int64, device=dev) for r, c in enumerate(counts)])
+            return (int(sum(counts[:rank])), int(sum(counts)), torch.cat(parts, dim=0).to(out_dev),
+                    owner.to(out_dev))
+    if counts is None:
+        cnt = torch.tensor([k], dtype=torch.int64, device=dev)
+        gathered_cnt = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(gathered_cnt, cnt, group=group)
+        counts = [int(c.item()) for c in gathered_cnt]
+    kmax = max(max(counts), 1)
     padded = torch.zeros((kmax, C), dtype=table.dtype, device=dev)
-    if nclusters:
-        padded[: int(nclusters)] = table[: int(nclusters)].reshape(int(nclusters), C)
+    if k:
+        padded[:k] = table[:k].reshape(k, C)
     gathered = [torch.zeros_like(padded) for _ in range(world)]
     dist.all_gather(gathered, padded, group=group)
     parts = [g[:c] for g, c in zip(gathered, counts)]

@@ -241,6 +241,14 @@ assert torch.equal(glob, exp)
 off2, total2, glob2, owner2 = tiles.reconcile(0 if rank == 0 else 4, torch.ones((4, 2)) * rank)
 assert total2 == 4 and off2 == 0 and owner2.tolist() == [1, 1, 1, 1]
 assert tiles.tiles_of_rank(5, rank, world) == ([0, 1, 2] if rank == 0 else [3, 4])
+# more clusters on one rank than the first exchange carries: the exactly sized second exchange, same result;
+# and a table whose dtype cannot carry the count (integers): the two-step form from the start
+tiles.RECONCILE_CAP = 2
+off3, total3, glob3, owner3 = tiles.reconcile(k, table)
+assert (off3, total3) == (off, total) and torch.equal(glob3, exp) and owner3.tolist() == [0, 0, 0, 1, 1]
+tiles.RECONCILE_CAP = 1024
+off4, total4, glob4, owner4 = tiles.reconcile(k, table.to(torch.int64))
+assert (off4, total4) == (off, total) and torch.equal(glob4, exp.to(torch.int64))
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
