@@ -103,8 +103,8 @@ def algorithmic_bytes(name, N, NF):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=100_000_000)
     ap.add_argument("--kind", default="corridor", choices=["corridor", "uniform"])
     ap.add_argument("--frame", default="offset", choices=["offset", "local"],
