@@ -1,0 +1,27 @@
+"""Statistics of the centroid walk per column (level-2 batches, exactly added blocks, descents) for the two frames.
+python tools/walk_probe.py [points]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pointcloudhookup_amd import _lib, ops, synth  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
+L = _lib.lib()
+for offset in (True, False):
+    x = synth.corridor_torch(n, seed=synth.SEED0 + 2, kind="corridor", offset=offset, device="cuda", dtype=torch.float32)
+    ops.mean_seq_f32(x)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    out = ops.mean_seq_f32(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) * 1e3
+    ws = ops._workspace(L.pch_mean_seq_f32_ws_bytes(n), x.device)
+    st = ws[:64].view(torch.int32).cpu().numpy().reshape(4, 4)[:3]
+    print(f"frame {'offset' if offset else 'local'}: {dt:.2f} ms, mean {out.cpu().numpy()}")
+    for c, name in enumerate("xyz"):
+        print(f"  column {name}: batches {st[c, 0]}, exact blocks {st[c, 2]}, descents {st[c, 3]}")
+    del x
