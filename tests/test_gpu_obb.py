@@ -142,3 +142,23 @@ def test_tower_table_fast_mode_against_exact_mode(cuda):
         assert min(d, 180.0 - d) < 2.0
     with pytest.raises(ValueError):
         pipeline.tower_table(cl, obb_mode="approximate")
+
+
+def test_shell_argument_checks_and_small_inputs(cuda):
+    rng = np.random.default_rng(2)
+    # no clusters at all, and clusters that are all below the pre-filter's size: everything is kept
+    pts = torch.from_numpy(rng.normal(size=(100, 3)).astype(np.float32)).cuda()
+    perm = torch.arange(100, dtype=torch.int32, device="cuda")
+    assert ops.obb_shell(pts, perm, torch.zeros(1, dtype=torch.int64, device="cuda"), 0).numel() == 0
+    offs = torch.tensor([0, 40, 100], dtype=torch.int64, device="cuda")
+    assert ops.obb_shell(pts, perm, offs, 2).cpu().numpy().all()
+    with pytest.raises(ValueError):
+        ops.obb_shell(pts, perm, offs, 3)                           # offsets do not match the cluster count
+    with pytest.raises(TypeError):
+        ops.obb_shell(pts.cpu(), perm, offs, 2)                     # no CPU fallback
+    # a cluster made of one repeated point / a segment: nothing can be proven interior, nothing is dropped
+    same = np.repeat(rng.normal(size=(1, 3)), 5000, axis=0)
+    seg = np.outer(np.linspace(0, 1, 5000), [3.0, 4.0, 12.0])
+    dP, perm2, offs2, clusters = _grouped([same, seg], rng, offset=(0.0, 0.0, 0.0), noise=10)
+    keep = ops.obb_shell(dP, perm2, offs2, 2).cpu().numpy()
+    assert keep.all()

@@ -569,3 +569,20 @@ def test_exact_mode_with_native_search_is_the_python_loop_bit_for_bit():
                     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     with pytest.raises(ValueError):
         list(obb.boxes_of(clouds, "unsorted", search="fast"))
+
+
+def test_native_search_edge_cases():
+    from pointcloudhookup_amd import ops
+    # no hulls
+    best, vol = ops.obb_search(np.zeros((0, 3)), [0], np.zeros((0, 2)), [0])
+    assert best.shape == (0,) and vol.shape == (0,)
+    # a hull without candidates and a flat one (every projection has a rectangle, the volume is zero)
+    sq = np.array([[0, 0, 0], [1, 0, 0], [1, 2, 0], [0, 2, 0]], dtype=np.float64)
+    best, vol = ops.obb_search(np.vstack([sq, sq]), [0, 4, 8], np.array([[0.0, 0.0]]), [0, 0, 1])
+    assert best.tolist() == [-1, 0] and vol[0] == 0.0
+    with pytest.raises(ValueError):
+        ops.obb_search(sq, [0, 3], np.zeros((1, 2)), [0, 1])            # offsets do not cover the arrays
+    # three collinear vertices: no rectangle in that projection -> inf, never chosen over a real one
+    line = np.array([[0, 0, 0], [1, 1, 0], [2, 2, 0]], dtype=np.float64)
+    best, vol = ops.obb_search(line, [0, 3], np.array([[0.0, 0.0]]), [0, 1])
+    assert best.tolist() == [-1] and np.isinf(vol[0])
