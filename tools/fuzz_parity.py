@@ -11,6 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import dbscan as odb                      # noqa: E402
 from oracle import ground_filter as ogf               # noqa: E402
+from oracle import voxel as ovx                       # noqa: E402
 from pointcloudhookup_amd import ops                  # noqa: E402
 from pointcloudhookup_amd._lib import PchError        # noqa: E402
 
@@ -19,7 +20,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 dev = torch.device("cuda:0")
 t_end = time.time() + budget
-stats = dict(filter=0, dbscan=0, mean=0)
+stats = dict(filter=0, dbscan=0, voxel=0)
 
 
 def cloud(n):
@@ -62,6 +63,23 @@ while time.time() < t_end:
     assert got["count"] == len(ref["filtered"]) and got["used_fallback"] == ref["used_fallback"], ("count", n, it)
     assert np.array_equal(got["points"].cpu().numpy().view(np.uint32), ref["filtered"].view(np.uint32)), ("points", n, it)
     stats["filter"] += 1
+    # voxel stage: random voxel size / chunking on the float64 view of the same cloud (quantised like LAS in half of
+    # the cases, which puts coordinates exactly on voxel faces)
+    if it % 3 == 0 and n >= 2:
+        p64 = raw.astype(np.float64)
+        if rng.integers(0, 2):
+            p64 = np.round(p64, int(rng.integers(1, 4)))
+        voxel = float(rng.choice([0.05, 0.1, 0.2, 0.25, 1.0, 7.3]))
+        vchunk = int(rng.choice([0, 1000, 4096, 4097, 50000, 500000]))
+        ext = (p64.max(axis=0) - p64.min(axis=0)).max()
+        if np.isfinite(p64).all() and ext / voxel < 2.0e6:
+            ridx, rmean, rcount, roffs = ovx.voxel_down_sample_chunked(p64, voxel, vchunk if vchunk else len(p64))
+            vi, vm, vc, vo = ops.voxel_downsample(torch.from_numpy(p64).to(dev), voxel, vchunk)
+            assert np.array_equal(vo.cpu().numpy(), roffs), ("voxel offsets", n, voxel, vchunk, it)
+            assert np.array_equal(vi.cpu().numpy(), ridx), ("voxel idx", n, voxel, vchunk, it)
+            assert np.array_equal(vc.cpu().numpy(), rcount), ("voxel count", n, voxel, vchunk, it)
+            assert np.array_equal(vm.cpu().numpy().view(np.uint64), rmean.view(np.uint64)), ("voxel mean", n, voxel, vchunk, it)
+            stats["voxel"] += 1
     # clustering on a bounded subset (the C oracle is all-pairs)
     m = min(len(ref["filtered"]), int(rng.choice([500, 3000, 12000])))
     if m >= 2:
