@@ -85,6 +85,9 @@ def algorithmic_bytes(name, N, NF):
     table = {
         "mean_summary": 16 * N, "sel_hist0": 4 * N, "sel_hist1": 4 * N, "sel_hist2": 4 * N,
         "sel_next": 4 * N, "gf_compact": 4 * N + 8 * NF + 16 * NF,    # z column, x/y of survivors, rows + index out
+        # bracketed select: the column once (sel_bracket), a 1/64 sample written and read; with the bracket in place
+        # sel_hist0/1/2 and sel_next read the candidates (~1 % of N) instead of the 4 N priced above
+        "sel_bracket": 4 * N, "sel_sample": 8 * (N // 64),
         # chunk sort: rows in (12) three times (box sweep, histogram sweep, pass 0), 16-byte rows through the
         # passes, rows + 8-byte keys out, head flags: 100 B per point at 2 passes (keys relative to the chunk's box)
         "db_chunksort": 100 * NF,
