@@ -1,13 +1,23 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: ground filter + tower clustering on a synthetic corridor.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--kind corridor|uniform]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode stream|tiled] [--points P] [--kind corridor|uniform]
 
 One "step" = one pass of stages B + C + D0 (float32 centroid/centring, percentile height
 filter, chunked exact DBSCAN, label grouping) over one resident float32 [P,3] tile per GPU.
-Prints ONE JSON line (rank 0).  N > 1 is launched by torch.distributed.run, one rank per GPU;
-every rank owns an independent tile (weak scaling) and the only collective is the label /
-cluster-table reconciliation of pointcloudhookup_amd/tiles.py.
+Prints ONE JSON line (rank 0).  One rank per GPU: under torch.distributed.run (RANK / WORLD_SIZE in the
+environment) this process IS a rank; started plainly with --gpus N > 1 it starts the N ranks itself
+(`python -m torch.distributed.run ...` as a child, before anything here touches the GPU) and relays rank 0's line.
+
+--mode stream (default; BASELINE configs[2] per GPU): every rank owns an independent 100 M-point tile, the
+  reference's 50 000-row chunked DBSCAN; the only collective is the cluster-table reconciliation
+  (tiles.reconcile).  Weak scaling.  The default line also carries a `tiled` object: the config-4 path below on
+  --tiled-points-per-gpu points per rank (50 M: at 8 GPUs exactly BASELINE configs[3]), so that the scaling runs
+  show the real cross-tile path over RCCL.
+--mode tiled (BASELINE configs[3]): ONE corridor spread over the ranks as x-tiles + halo; chained float32 centroid,
+  percentile threshold across the ranks, per-tile filter, global DBSCAN per tile and the cross-tile label
+  reconciliation (tiles.tiled_step).  --points is then the WHOLE cloud (default 400 M); each rank generates only
+  its own tile + halo.
 """
 from __future__ import annotations
 
@@ -103,12 +113,171 @@ def algorithmic_bytes(name, N, NF):
     return table.get(name)
 
 
+HALO = 2 * EPS + 1.0       # tile overlap: 2*eps (exact core flags eps beyond the edge) + the float32 rounding of
+                           # EPSG-scale x coordinates (ulp 0.03 m) between the raw frame that cuts the tiles and
+                           # the centred frame that is clustered
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a launcher: start `torch.distributed.run` as a CHILD process - this process has not
+    imported torch, let alone touched the GPU - relay rank 0's JSON line and exit with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["PCH_BENCH_PARENT_TORCH"] = str("torch" in sys.modules)     # must be False: the parent stays off the GPU
+    if env.get("PCH_BENCH_SINGLE_DEVICE"):
+        env.setdefault("PCH_DIST_BACKEND", "gloo")          # RCCL refuses two ranks on one device
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited without a result line\n")
+        rc = 1
+    if line is not None and rc == 0:
+        print(line)
+    sys.exit(rc)
+
+
+def dryrun(args):
+    """PCH_BENCH_DRYRUN=1: the launcher path without a GPU (tests/test_host.py): every rank joins a gloo group,
+    the ranks count themselves with one all_reduce and rank 0 prints a result line.  PCH_BENCH_DRYRUN=fail:<r> makes
+    rank r exit with an error instead - the launcher must then exit non-zero without a line."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    how = os.environ["PCH_BENCH_DRYRUN"]
+    if how.startswith("fail:") and int(how[5:]) == rank:
+        raise SystemExit(f"rank {rank}: failing on purpose")
+    seen = torch.ones(1, dtype=torch.int64)
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist.all_reduce(seen)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "dryrun", "value": 0.0, "n_gpus": world, "ranks_seen": int(seen.item()),
+                          "mode": args.mode, "steps": args.steps, "warmup": args.warmup,
+                          "parent_imported_torch": os.environ.get("PCH_BENCH_PARENT_TORCH")}))
+
+
+def run_tiled(points_total, kind, frame, rank, world, dev, steps, warmup, seed, verify=False):
+    """BASELINE configs[3] on `world` ranks: every rank generates its own x-tile + halo of ONE strip corridor of
+    points_total points and runs tiles.tiled_step on it.  Timed like the main loop (barrier + synchronize on both
+    sides, max over ranks).  Returns the result dict on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    from pointcloudhookup_amd import synth, tiles
+    import numpy as np
+    t = synth.corridor_tile_torch(points_total, rank, world, HALO, seed=seed, kind=kind, offset=(frame == "offset"),
+                                  device=dev, dtype=torch.float32)
+    tile, own = t["points"], t["own"]
+    rows, total = tiles.global_rows(t["local_row"], t["n_own"])
+    assert total == points_total, (total, points_total)
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def step(tm=None):
+        return tiles.tiled_step(tile, rows, own, total, t["x_lo"], t["x_hi"], EPS, MIN_POINTS, halo=HALO, timings=tm)
+
+    for _ in range(max(warmup, 1)):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tm = {}
+    for _ in range(2):                                     # phase split on two extra steps (adds syncs: not timed above)
+        step(tm)
+    barrier()
+    phases = torch.tensor([elapsed, tm["filter_ms"] / 2, tm["fit_ms"] / 2, tm["reconcile_ms"] / 2,
+                           float(tile.shape[0])], dtype=torch.float64)
+    kept_own = torch.tensor([int(res["own"].sum())], dtype=torch.int64)
+    if world > 1:
+        on_dev = dist.get_backend() == "nccl"
+        phases = phases.to(dev) if on_dev else phases
+        kept_own = kept_own.to(dev) if on_dev else kept_own
+        dist.all_reduce(phases, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kept_own, op=dist.ReduceOp.SUM)
+    verified = None
+    if verify:
+        # the check (not timed): rank 0 ALONE builds the whole cloud, runs the single-GPU path over it (fused filter +
+        # one global DBSCAN) and compares centroid and threshold bit for bit and every rank's owned labels
+        from pointcloudhookup_amd import ops
+        o = res["own"]
+        mine = (res["rows"][o].cpu(), res["labels"][o].cpu(), res["centroid"], np.float32(res["threshold"]))
+        parts = [mine]
+        if world > 1:
+            parts = [None] * world if rank == 0 else None
+            dist.gather_object(mine, parts, dst=0)
+        if rank == 0:
+            full = torch.cat([synth.corridor_strip_torch(points_total, s, seed, kind, frame == "offset", dev)
+                              .to(torch.float32) for s in range(synth.n_strips(points_total))])
+            gf = ops.ground_filter(full, want_index=True)
+            want, _, k1 = ops.dbscan(gf["points"], EPS, MIN_POINTS, 0)
+            want_full = torch.full((full.shape[0],), -2, dtype=torch.int32, device=dev)
+            want_full[gf["index"].long()] = want
+            seen = torch.zeros(full.shape[0], dtype=torch.int32, device=dev)
+            ok = int(res["nclusters"]) == int(k1)
+            for rws, lab, cen, thr in parts:
+                ok = ok and np.array_equal(np.asarray(cen, np.float32).view(np.uint32), gf["centroid"].view(np.uint32))
+                ok = ok and np.float32(thr).view(np.uint32) == np.float32(gf["threshold"]).view(np.uint32)
+                ok = ok and bool(torch.equal(lab.to(dev), want_full[rws.to(dev)]))
+                seen[rws.to(dev)] += 1
+            kept_mask = want_full > -2
+            ok = ok and bool(torch.equal(seen, kept_mask.to(torch.int32)))      # every kept row owned exactly once
+            verified = bool(ok)
+            del full, gf, want, want_full, seen
+    if rank != 0:
+        return None
+    ph = phases.cpu().tolist()
+    return {"verified_against_single_gpu_run": verified,
+            "workload": f"{points_total / 1e6:g} M-pt strip corridor ({kind}) cut into {world} x-tile(s) + "
+                        f"{HALO:g} m halo, chained float32 centroid + shared percentile + filter + global "
+                        f"DBSCAN(eps={EPS:g}, min_samples={MIN_POINTS}) per tile + cross-tile label reconciliation "
+                        "(BASELINE configs[3] at 400 M / 8 GPUs)",
+            "points_total": int(points_total), "ranks_seen": int(dist.get_world_size()) if world > 1 else 1,
+            "backend": dist.get_backend() if world > 1 else "none",
+            "devices": "one GPU shared by all ranks (rehearsal)" if os.environ.get("PCH_BENCH_SINGLE_DEVICE") else "one GPU per rank",
+            "steps": steps, "ms_per_step": round(1e3 * ph[0] / steps, 3),
+            "Mpts_per_s": round(points_total * steps / ph[0] / 1e6, 1),
+            "phase_ms_max_over_ranks": {"centroid_chain+threshold+filter": round(ph[1], 3),
+                                        "local_fit": round(ph[2], 3), "reconciliation": round(ph[3], 3)},
+            "largest_tile_points": int(ph[4]), "kept_points": int(kept_own.item()),
+            "clusters": int(res["nclusters"]), "used_fallback": bool(res["used_fallback"]),
+            "centroid": [float(v) for v in res["centroid"]], "threshold": float(res["threshold"])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--points", type=int, default=100_000_000)
+    ap.add_argument("--mode", default="stream", choices=["stream", "tiled"])
+    ap.add_argument("--points", type=int, default=None,
+                    help="stream: points per GPU (default 100 M); tiled: points of the WHOLE cloud (default 400 M)")
+    ap.add_argument("--verify", action="store_true",
+                    help="tiled runs: rank 0 rebuilds the whole cloud, runs the single-GPU path and checks centroid, "
+                         "threshold and every rank's owned labels against it (not timed)")
+    ap.add_argument("--tiled-points-per-gpu", type=int, default=50_000_000,
+                    help="size of the config-4 side run of the default mode (x world = its cloud)")
     ap.add_argument("--kind", default="corridor", choices=["corridor", "uniform"])
     ap.add_argument("--frame", default="offset", choices=["offset", "local"],
                     help="offset: EPSG:4547-scale coordinates like the reference's data (default); "
@@ -123,18 +292,61 @@ def main():
                          "(voxel downsample -> extract_towers); reported as a side value, 'skipped' without a file")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
+    if args.points is None:
+        args.points = 100_000_000 if args.mode == "stream" else 400_000_000
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args, sys.argv[1:])                     # never returns
+    if env_world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: start it either plainly "
+                         f"(it launches its own ranks) or under torch.distributed.run with --nproc-per-node {args.gpus}")
+    if os.environ.get("PCH_BENCH_SINGLE_DEVICE") and env_world > 4:
+        # a rehearsal mode (ranks sharing one device over gloo); five processes on one GPU have stalled before
+        #  - refused before any GPU work
+        raise SystemExit("bench.py: PCH_BENCH_SINGLE_DEVICE supports at most 4 ranks on the one device")
+
+    if os.environ.get("PCH_BENCH_DRYRUN"):
+        return dryrun(args)
 
     import torch
     import torch.distributed as dist
     from pointcloudhookup_amd import ops, pipeline, synth, tiles
 
-    rank, world, local = tiles.init_from_env()
+    rank, world, local = tiles.init_from_env(timeout_s=600)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if os.environ.get("PCH_BENCH_SINGLE_DEVICE"):           # rehearsal of the N>1 path on a 1-GPU box
         local = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s) visible "
+                         "(PCH_BENCH_SINGLE_DEVICE=1 rehearses up to 4 ranks on one device over gloo)")
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
+    if args.mode == "tiled":                                 # BASELINE configs[3]: the whole line is the tiled run
+        seed = synth.SEED0 + 3
+        ops.set_profiling(False)
+        res = run_tiled(int(args.points), args.kind, args.frame, rank, world, dev, args.steps, args.warmup, seed,
+                        verify=args.verify)
+        if rank == 0 and res.get("verified_against_single_gpu_run") is False:
+            print(json.dumps({"error": "tiled labels differ from the single-GPU run", "tiled": res}), file=sys.stderr)
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit(4)
+        if rank == 0:
+            out = {"metric": "Mpts/s ground-filter+tower-cluster, 100 M-pt corridor; % HBM roofline on kNN",
+                   "value": res["Mpts_per_s"], "unit": "Mpts/s", "n_gpus": world, "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+                   "scaling": "strong", "vs_baseline": None, "dtype": "f32 (filter) + f64 (distance predicate)",
+                   "data": "synthetic",
+                   "config": {"workload": res["workload"], "points_total": res["points_total"],
+                              "frame": "global-offset (+437000,+3139000,+80)" if args.frame == "offset" else "local",
+                              "seed": seed, "parallelism": f"x-tiles x{world}"},
+                   "tiled": res, "roofline": None, "cpu_baseline": None,
+                   "note": "roofline and cpu_baseline are carried by the default (--mode stream) line"}
+            print(json.dumps(out))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     N = int(args.points)
     seed = synth.SEED0 + 2 + rank
     raw = synth.corridor_torch(N, seed=seed, kind=args.kind, offset=(args.frame == "offset"), device=dev,
@@ -153,8 +365,6 @@ def main():
         if world > 1:
             dist.barrier()
 
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     # warm-up steps are profiled in full to learn which kernels matter; the timed steps then record
     # hipEvents only around those (two event records per launch are not free on the host)
     ops.set_profiling(True)
@@ -183,6 +393,15 @@ def main():
         elapsed = float(t.item())
     NF = int(cl["ground"]["count"])
     K = int(cl["nclusters"])
+
+    # ---- config-4 side run (every rank takes part): ONE cloud of world x tiled-points-per-gpu points
+    tiled_res = None
+    if not args.no_side and args.tiled_points_per_gpu > 0:
+        try:
+            tiled_res = run_tiled(int(args.tiled_points_per_gpu) * world, args.kind, args.frame, rank, world, dev,
+                                  max(3, min(args.steps, 10)), 2, synth.SEED0 + 3, verify=args.verify)
+        except Exception as e:                               # never lose the main line
+            tiled_res = {"error": f"{type(e).__name__}: {e}"}
 
     if rank != 0:
         if world > 1:
@@ -259,6 +478,7 @@ def main():
         "kernels": [dict(name=r[0], avg_ms=round(r[1], 4), launches_per_step=r[2] / args.steps,
                          ms_per_step=round(r[3], 4)) for r in kernels[:12]],
         "knn_cell_occupancy": occ,
+        "tiled": tiled_res,
     }
 
     # ---- side measurements (none of them in `value`)

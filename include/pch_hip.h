@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PCH_VERSION 200
+#define PCH_VERSION 300
 
 #define PCH_OK               0
 #define PCH_ERR_ARG         -1   /* bad argument (null pointer, negative size, eps<=0 ...) */
@@ -42,6 +42,17 @@ extern "C" {
 #define PCH_ERR_HIP         -3   /* a HIP runtime call failed */
 #define PCH_ERR_RANGE       -4   /* grid does not fit the 64-bit cell/voxel key */
 #define PCH_ERR_NODEVICE    -5   /* no gfx950 device visible */
+#define PCH_ERR_TIMEOUT     -6   /* a device-side wait between workgroups ran out of its budget (see below) */
+
+/* Device-side waits are bounded.  The order-preserving compactions (pch_ground_filter_f32, pch_filter_gt_f32,
+ * pch_crop_aabb_f64) and the voxel finisher (pch_voxel_downsample_f64) chain their workgroups by a single-pass
+ * look-back: a workgroup polls the status words of the workgroups in front of it.  Every such poll loop has a
+ * wall-clock budget (4 s); a workgroup that exceeds it gives up, the kernel drains, and the call's count word
+ * (*out_count / *out_m, device memory) reads NEGATIVE instead of holding a count - the outputs are then
+ * undefined.  Entry points that read the count on the host themselves (pch_tower_clusters_f32) return
+ * PCH_ERR_TIMEOUT; callers of the asynchronous entry points must test the sign when they read the count
+ * (pointcloudhookup_amd/ops.py does and raises).  Nothing in normal operation comes near the budget: it exists
+ * so that a GPU shared with other processes can never be left with a resident spinning grid. */
 
 int         pch_version(void);
 const char* pch_last_error(void);
@@ -123,6 +134,19 @@ int pch_cast_f64_f32(const double* in, int64_t count, float* out, void* stream);
 size_t pch_mean_seq_f32_ws_bytes(int64_t n);
 int pch_mean_seq_f32(const float* xyz, int64_t n, float* out_centroid,
                      void* ws, size_t ws_bytes, void* stream);
+/* One file-order SHARD of that sequential sum (config 4: every rank holds a consecutive slice of the rows and the
+ * three running sums travel down the line, 12 bytes per hop): continues the float32 running sums sum_in3 (device
+ * float[3]; NULL = +0.0, the first shard) over these n rows, exactly as numpy's loop would.
+ *   total_n == 0: out3 = the running sums AFTER the rows (hand them to the next shard);
+ *   total_n  > 0: out3 = running sums / float32(total_n) - the centroid of all total_n rows (last shard).
+ * Shards chained in file order give np.mean(concatenation, axis=0) bit for bit; n == 0 passes the sums through.
+ * phase: 0 = everything; 1 = only the summary tables of these rows (they do not depend on sum_in3: every rank
+ * builds them at once, sum_in3 / out3 are ignored); 2 = only the short serial walk over the tables a phase-1 call
+ * left in the SAME workspace (the caller keeps that workspace untouched in between) - so that along a chain of
+ * shards only the walks (~0.1-0.3 ms each) are serial, not the passes over the rows.
+ * Workspace: pch_mean_seq_f32_ws_bytes(n).  Replaces: utils/tower_extraction.py:63 on a sharded array. */
+int pch_mean_seq_partial_f32(const float* xyz, int64_t n, const float* sum_in3, int64_t total_n,
+                             float* out3, int32_t phase, void* ws, size_t ws_bytes, void* stream);
 /* same result from one workgroup adding element by element (O(n) serial; kept only to
  * cross-check the parallel algorithm above) */
 int pch_mean_seq_serial_f32(const float* xyz, int64_t n, float* out_centroid, void* stream);
@@ -212,12 +236,28 @@ int pch_dbscan_f32(const float* xyz, int64_t n, double eps, int32_t min_samples,
  * -1" (border points must be re-decided: the order of the ids may have changed).  Used by the cross-tile
  * reconciliation (pointcloudhookup_amd/tiles.py): clusters cut by a tile edge are united and renumbered
  * globally, which generalises the per-chunk label offsets of utils/tower_extraction.py:113-116.
- * map [nmap] int32 (device): new id per old id (-1 = drop).  labels [n] int32: in/out. */
+ * map [nmap] int32 (device): new id per old id (-1 = drop).  labels [n] int32: in/out.
+ * Workspace rule: the library remembers, per thread, the workspace of the last pch_dbscan_f32 call; ANY pch_*
+ * call of that thread whose workspace overlaps it forgets it again, and this call then returns PCH_ERR_ARG
+ * ("must follow pch_dbscan_f32 ... untouched workspace") rather than following overwritten indices.  Give the
+ * fit a workspace of its own if other calls run between the fit and the relabel (ops.DbscanFit does). */
 int pch_dbscan_relabel_i32(const int32_t* map, int32_t nmap, int64_t n, int32_t* labels,
                            void* ws, size_t ws_bytes, void* stream);
 /* Smallest core row of every cluster of that same last call (the row that gives a cluster its number in
  * sklearn's sweep): out_rows [nclusters] int32, ascending.  Same workspace rule as the relabel call. */
 int pch_dbscan_first_core_rows_i32(int64_t n, int32_t* out_rows, void* ws, size_t ws_bytes, void* stream);
+
+/* The (row, cluster) pairs a tile publishes to its neighbour for the cross-tile reconciliation (config 4,
+ * pointcloudhookup_amd/tiles.py): of that same last fit, ONE pair per grid cell that holds a core point with
+ * x_lo <= x < x_hi - the cell's smallest such row and the cell's cluster id.  All core points of a cell lie within
+ * eps of each other, so they share a cluster in any tile that sees them: a pair per cell carries what a pair per
+ * point would (a tower on a tile edge: hundreds of pairs instead of hundreds of thousands).  Call it BEFORE
+ * pch_dbscan_relabel_i32 (it reports the fit's own ids).  out_pairs [cap,2] int32 in no particular order;
+ * *out_count (device int32) = number of such cells, which may exceed cap (then only cap pairs were stored: call
+ * again with a larger buffer).  Same workspace rule as the relabel call.
+ * Generalises: the per-chunk label offsets of utils/tower_extraction.py:113-116 to tiles that share points. */
+int pch_dbscan_strip_pairs_i32(int64_t n, float x_lo, float x_hi, int32_t cap, int32_t* out_pairs,
+                               int32_t* out_count, void* ws, size_t ws_bytes, void* stream);
 
 /* First row of xyz [n,3] float32 that holds NaN or +-inf, -1 if every row is finite.
  * Replaces: sklearn's input validation inside DBSCAN.fit (check_array, ensure_all_finite), which
@@ -290,6 +330,11 @@ size_t pch_crop_aabb_ws_bytes(int64_t n);
 int pch_crop_aabb_f64(const double* xyz, int64_t n, const double* min3_host, const double* max3_host,
                       double* out_points, int64_t* out_index, int64_t* out_count,
                       void* ws, size_t ws_bytes, void* stream);
+/* Self-test of the bounded wait: launches four look-back tiles of which one never publishes and returns
+ * PCH_ERR_TIMEOUT when the tiles behind it gave up within budget_ms (1..2000) as designed; PCH_ERR_HIP when they did
+ * not.  dev_scratch: >= 256 bytes of device memory.  Synchronises.  Not part of the data path (tests only). */
+int pch_selftest_lookback_timeout(int budget_ms, void* dev_scratch, size_t scratch_bytes, void* stream);
+
 /* Preview decimation: k distinct rows chosen by a seeded pseudo-random bijection of the row range.
  * Replaces: points[np.random.choice(len(points), k, replace=False)] (pyGUI_towers_test.py:174-177 with k =
  * 200 000, ui/vtk_widget.py:115-118 with k = 500 000).  numpy's draw is unseeded there, so parity is a

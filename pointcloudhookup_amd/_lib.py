@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libpch_hip.so")
 
 PCH_OK = 0
 ERR_NAMES = {-1: "PCH_ERR_ARG", -2: "PCH_ERR_WORKSPACE", -3: "PCH_ERR_HIP",
-             -4: "PCH_ERR_RANGE", -5: "PCH_ERR_NODEVICE"}
+             -4: "PCH_ERR_RANGE", -5: "PCH_ERR_NODEVICE", -6: "PCH_ERR_TIMEOUT"}
 
 
 class PchError(RuntimeError):
@@ -41,6 +41,7 @@ _SIGS = {
     "pch_cast_f64_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pch_mean_seq_f32_ws_bytes": (_sz, [_i64]),
     "pch_mean_seq_f32": (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "pch_mean_seq_partial_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _sz, _vp]),
     "pch_mean_seq_serial_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pch_percentile_f32_ws_bytes": (_sz, [_i64]),
     "pch_percentile_f32": (C.c_int, [_vp, _i64, _i64, _vp, _f64, _vp, _vp, _sz, _vp]),
@@ -55,6 +56,7 @@ _SIGS = {
     "pch_first_nonfinite_row_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pch_dbscan_relabel_i32": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _sz, _vp]),
     "pch_dbscan_first_core_rows_i32": (C.c_int, [_i64, _vp, _vp, _sz, _vp]),
+    "pch_dbscan_strip_pairs_i32": (C.c_int, [_i64, _f32, _f32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "pch_dbscan_ws_bytes": (_sz, [_i64]),
     "pch_dbscan_f32": (C.c_int, [_vp, _i64, _f64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pch_segment_by_label_ws_bytes": (_sz, [_i64, _i32]),
@@ -62,6 +64,7 @@ _SIGS = {
     "pch_crop_aabb_ws_bytes": (_sz, [_i64]),
     "pch_crop_aabb_f64": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pch_decimate_f64": (C.c_int, [_vp, _i64, _i64, C.c_uint64, _vp, _vp, _vp]),
+    "pch_selftest_lookback_timeout": (C.c_int, [C.c_int, _vp, _sz, _vp]),
     "pch_obb_shell_ws_bytes": (_sz, [_i32]),
     "pch_obb_shell_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _sz, _vp]),
     "pch_obb_search_f64": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
@@ -123,6 +126,19 @@ def lib():
 def check(rc):
     if rc != PCH_OK:
         raise PchError(rc, lib().pch_last_error().decode("utf-8", "replace"))
+
+
+PCH_ERR_TIMEOUT = -6
+
+
+def check_count(count, what):
+    """A count word the device wrote reads negative when a bounded device-side wait ran out of its budget
+    (include/pch_hip.h, PCH_ERR_TIMEOUT): the outputs are undefined, so this raises instead of returning them."""
+    count = int(count)
+    if count < 0:
+        raise PchError(PCH_ERR_TIMEOUT, f"{what}: a device-side look-back wait ran out of its budget "
+                                        "(is the GPU shared with other processes?); outputs are undefined")
+    return count
 
 
 def get_profile(cap=128):

@@ -52,6 +52,11 @@ struct DeviceGuard {
 };
 // device the calling thread currently has selected, clamped to [0, PCH_MAX_DEVICES)
 int current_device_slot();
+// Per-thread HIP objects (events, pinned peek buffers, side streams) are released by thread-local destructors.
+// For the main thread those run during process exit, when the HIP runtime (owned by torch's libamdhip64) may
+// already be tearing down: calling into it then is undefined.  False on the main thread and once exit has begun;
+// the destructors then leave the objects to the operating system.
+bool may_release_hip_objects();
 #define PCH_DEVICE_GUARD(ptr)                 \
     ::pch::DeviceGuard _pch_guard(ptr);       \
     if (_pch_guard.rc != PCH_OK) return _pch_guard.rc
@@ -59,13 +64,22 @@ int current_device_slot();
 // ---------------------------------------------------------------- workspace arena
 // The same plan function is run once with base == nullptr (size query) and once with the
 // caller's buffer, so *_ws_bytes() can never disagree with the real carve-up.
+//
+// A workspace whose contents a LATER call continues (pch_dbscan_relabel_i32 / pch_dbscan_first_core_rows_i32 on
+// the grid pch_dbscan_f32 left behind) is remembered per thread.  Every entry point carves its workspace through
+// an Arena, and carving a range that overlaps the remembered one drops it (ws_touched, pch_dbscan.hip): the
+// continuation then fails with PCH_ERR_ARG instead of following overwritten indices on the device.  The
+// continuation itself builds its Arena with continues = true.
+void ws_touched(const void* base, size_t bytes);
 struct Arena {
     char*  base;
     size_t cap;
     size_t off;
     bool   overflow;
-    explicit Arena(void* b = nullptr, size_t c = 0)
-        : base(static_cast<char*>(b)), cap(c), off(0), overflow(false) {}
+    explicit Arena(void* b = nullptr, size_t c = 0, bool continues = false)
+        : base(static_cast<char*>(b)), cap(c), off(0), overflow(false) {
+        if (b && !continues) ws_touched(b, c);
+    }
     template <typename T>
     T* take(size_t count) {
         size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);

@@ -2,6 +2,10 @@
 #include "pch_common.h"
 
 #include <stdarg.h>
+#include <stdlib.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -16,6 +20,17 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static std::atomic<bool> g_exiting{false};
+static std::atomic<bool> g_exit_hook{false};
+static void note_exit() { g_exiting.store(true, std::memory_order_relaxed); }
+static void arm_exit_hook() {                       // first creation of a per-thread HIP object registers it
+    if (!g_exit_hook.exchange(true)) atexit(note_exit);
+}
+bool may_release_hip_objects() {
+    if (g_exiting.load(std::memory_order_relaxed)) return false;
+    return (long)syscall(SYS_gettid) != (long)getpid();     // the main thread's destructors run at process exit
+}
+
 struct ProfRec {
     const char* name;
     hipEvent_t  e0, e1;
@@ -24,10 +39,12 @@ struct ProfRec {
 static thread_local bool                 g_prof_on = false;
 static thread_local std::vector<ProfRec> g_recs;
 // HIP objects belong to the device that was current when they were made: the per-thread caches
-// below are kept per device (a thread may serve several GPUs) and are destroyed at thread exit.
+// below are kept per device (a thread may serve several GPUs) and are destroyed when a WORKER thread
+// exits (may_release_hip_objects: never from the main thread's destructors, never during process exit).
 struct EventPools {
     std::vector<hipEvent_t> pool[PCH_MAX_DEVICES];
     ~EventPools() {
+        if (!may_release_hip_objects()) return;
         for (auto& p : pool)
             for (hipEvent_t e : p) (void)hipEventDestroy(e);
     }
@@ -73,6 +90,7 @@ static hipEvent_t take_event(int slot) {
         return e;
     }
     hipEvent_t e = nullptr;
+    arm_exit_hook();
     (void)hipEventCreate(&e);
     return e;
 }
@@ -117,6 +135,7 @@ struct HostPeeks {
     HostPeek hp[PCH_MAX_DEVICES];
     HostPeeks() { for (auto& h : hp) h = {nullptr, nullptr, false}; }
     ~HostPeeks() {
+        if (!may_release_hip_objects()) return;
         for (auto& h : hp)
             if (h.ok) { (void)hipEventDestroy(h.ev); (void)hipHostFree(h.pinned); }
     }
@@ -125,6 +144,7 @@ HostPeek& host_peek() {
     static thread_local HostPeeks all;
     HostPeek& hp = all.hp[current_device_slot()];
     if (!hp.ok) {
+        arm_exit_hook();
         if (hipHostMalloc(&hp.pinned, 256, hipHostMallocDefault) == hipSuccess &&
             hipEventCreateWithFlags(&hp.ev, hipEventDisableTiming) == hipSuccess)
             hp.ok = true;

@@ -1479,6 +1479,44 @@ __global__ __launch_bounds__(DB_THREADS) void db_first_rows_k(const uint32_t* __
     }
 }
 
+// Cross-tile links (config 4): one representative per cell of the core points with x in [x_lo, x_hi) - the strip
+// around a tile edge.  All core points of a cell are mutually within eps (cell side eps/sqrt(3)), so they are one
+// cluster in ANY tile that holds them with exact core flags: one (row, cluster) pair per cell tells the
+// neighbouring tile everything the pairs of all its strip points would.  One wave per cell; cells whose core box
+// misses the strip are rejected from the cell table alone.
+__global__ __launch_bounds__(DB_THREADS) void db_strip_pairs_k(const float4* __restrict__ pts,
+                                                               const uint32_t* __restrict__ cell_start,
+                                                               const uint8_t* __restrict__ core_s,
+                                                               const uint32_t* __restrict__ cell_ncore,
+                                                               const float* __restrict__ cell_box,
+                                                               const int* __restrict__ cell_label, int m, float x_lo,
+                                                               float x_hi, int32_t cap, int32_t* __restrict__ out_pairs,
+                                                               int32_t* __restrict__ out_count) {
+    const int c = blockIdx.x * DB_WAVES + wave_id();
+    if (c >= m) return;                                   // wave-uniform
+    if (cell_ncore[c] == 0) return;
+    if (!(cell_box[6 * (int64_t)c + 3] >= x_lo && cell_box[6 * (int64_t)c] < x_hi)) return;
+    const int l = lane_id();
+    const uint32_t a = cell_start[c], b = cell_start[c + 1];
+    uint32_t best = 0xFFFFFFFFu;
+    for (uint32_t i = a + l; i < b; i += 64) {
+        if (!core_s[i]) continue;
+        const float4 p = pts[i];
+        if (p.x >= x_lo && p.x < x_hi) {
+            const uint32_t row = __float_as_uint(p.w);
+            best = row < best ? row : best;
+        }
+    }
+    best = wave_reduce_min(best);
+    if (l == 0 && best != 0xFFFFFFFFu) {
+        const int32_t slot = atomicAdd(out_count, 1);     // the count keeps growing beyond cap: the caller sees it
+        if (slot < cap) {
+            out_pairs[2 * slot] = (int32_t)best;
+            out_pairs[2 * slot + 1] = cell_label[c];
+        }
+    }
+}
+
 __global__ void db_finish_k(const uint32_t* __restrict__ total, int32_t* __restrict__ out_nclusters) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *out_nclusters = (int32_t)*total;
 }
@@ -1552,6 +1590,13 @@ static int db_sort_mode() {
 // what pch_dbscan_relabel_i32 needs to know about the run whose workspace it continues
 struct DbLastRun { void* ws; size_t ws_bytes; int64_t n; int m; DbGrid g; bool has_rowtab; };
 static thread_local DbLastRun g_last = {nullptr, 0, 0, 0, {}, false};
+
+void ws_touched(const void* base, size_t bytes) {
+    if (!g_last.ws) return;
+    const char* a0 = static_cast<const char*>(base);
+    const char* b0 = static_cast<const char*>(g_last.ws);
+    if (a0 < b0 + g_last.ws_bytes && b0 < a0 + bytes) g_last.ws = nullptr;
+}
 
 // host mirror of f32_unordered
 static float host_unordered(uint32_t k) {
@@ -1860,7 +1905,7 @@ extern "C" int pch_dbscan_first_core_rows_i32(int64_t n, int32_t* out_rows, void
         return PCH_ERR_ARG;
     }
     PCH_REQUIRE(out_rows != nullptr, "null output");
-    Arena a(ws, ws_bytes);
+    Arena a(ws, ws_bytes, true);
     DbWs w;
     db_plan(a, n, w);
     const int64_t nw = ceil_div(n, 32);
@@ -1868,6 +1913,28 @@ extern "C" int pch_dbscan_first_core_rows_i32(int64_t n, int32_t* out_rows, void
     const uint32_t* wrank = w.flag + ((nw + 63) & ~int64_t(63));
     PCH_LAUNCH("db_first_rows", db_first_rows_k, dim3((unsigned)ceil_div(nw, DB_THREADS)), dim3(DB_THREADS), 0,
                (hipStream_t)stream, bits, wrank, nw, out_rows);
+    return PCH_OK;
+}
+
+extern "C" int pch_dbscan_strip_pairs_i32(int64_t n, float x_lo, float x_hi, int32_t cap, int32_t* out_pairs,
+                                          int32_t* out_count, void* ws, size_t ws_bytes, void* stream) {
+    PCH_DEVICE_GUARD(out_count);
+    hipStream_t s = (hipStream_t)stream;
+    PCH_REQUIRE(n >= 0 && cap >= 0 && out_count && (cap == 0 || out_pairs), "bad argument");
+    PCH_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(int32_t), s));
+    if (n == 0 || !(x_lo < x_hi)) return PCH_OK;
+    if (g_last.ws != ws || g_last.ws_bytes != ws_bytes || g_last.n != n || ws == nullptr) {
+        set_error("pch_dbscan_strip_pairs_i32 must follow pch_dbscan_f32 of this thread on the same, untouched workspace");
+        return PCH_ERR_ARG;
+    }
+    Arena a(ws, ws_bytes, true);
+    DbWs w;
+    db_plan(a, n, w);
+    const int m = g_last.m;
+    PCH_LAUNCH("db_strip_pairs", db_strip_pairs_k, dim3((unsigned)ceil_div(m, DB_WAVES)), dim3(DB_THREADS), 0, s,
+               (const float4*)w.pts, (const uint32_t*)w.cell_start, (const uint8_t*)w.core_s,
+               (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, (const int*)w.cell_label, m, x_lo, x_hi, cap,
+               out_pairs, out_count);
     return PCH_OK;
 }
 
@@ -1881,7 +1948,7 @@ extern "C" int pch_dbscan_relabel_i32(const int32_t* map, int32_t nmap, int64_t 
         set_error("pch_dbscan_relabel_i32 must follow pch_dbscan_f32 of this thread on the same, untouched workspace");
         return PCH_ERR_ARG;
     }
-    Arena a(ws, ws_bytes);
+    Arena a(ws, ws_bytes, true);
     DbWs w;
     db_plan(a, n, w);
     const DbGrid g = g_last.g;

@@ -606,6 +606,7 @@ struct SideStreams {                                    // one per device this t
     SideStream ss[PCH_MAX_DEVICES];
     SideStreams() { for (auto& x : ss) x = {nullptr, nullptr, nullptr, false}; }
     ~SideStreams() {
+        if (!may_release_hip_objects()) return;
         for (auto& x : ss)
             if (x.ok) { (void)hipEventDestroy(x.ev_fork); (void)hipEventDestroy(x.ev_join); (void)hipStreamDestroy(x.s); }
     }
@@ -640,7 +641,7 @@ constexpr int GF_SLOTS   = 64;
 struct GfState {
     uint32_t total[2];                     // kept with threshold A (offset) / B (fallback)
     uint32_t use_b;
-    uint32_t pad;
+    uint32_t failed;                       // a look-back wait ran out of its budget (pch_lookback.h): count -> -1
     uint32_t ticket[2];                    // next logical tile of either sweep (order of arrival, see gf_compact_k)
     uint32_t pad2[2];
     uint32_t slots[2][GF_SLOTS][6];        // per sweep: ~min xyz (complemented) / max xyz as ordered uint32,
@@ -694,10 +695,14 @@ __global__ __launch_bounds__(GF_THREADS) void gf_compact_k(
     __syncthreads();
     const uint32_t T = wtot[0] + wtot[1] + wtot[2] + wtot[3];
     if (w == 0) {
-        const uint32_t e = gf_lookback(status, tile, T);
+        const uint32_t e0 = gf_lookback(status, tile, T);
+        const bool lb_failed = e0 == GF_LB_FAILED;
+        const uint32_t e = lb_failed ? 0u : e0;              // prefix 0 keeps the writes below inside the output
         if (l == 0) {
             excl_sh = e;
-            if (tile == (int64_t)gridDim.x - 1) {                // the last tile knows the total: it also decides
+            if (lb_failed) {
+                atomicOr(&st->failed, 1u);
+            } else if (tile == (int64_t)gridDim.x - 1) {         // the last tile knows the total: it also decides
                 st->total[WHICH] = e + T;                     // whether the fallback threshold applies
                 if (WHICH == 0) st->use_b = ((long long)(e + T) < min_keep) ? 1u : 0u;
             }
@@ -781,7 +786,7 @@ __global__ void gf_finalize_k(const GfState* __restrict__ st, const float* __res
         out_scalars[5] = use_b ? 1.0f : 0.0f;
         out_scalars[6] = __uint_as_float(st->total[0]);   // kept at the first threshold: the uint32 count's BITS
         out_scalars[7] = 0.0f;
-        *out_count = (int64_t)st->total[use_b];
+        *out_count = st->failed ? (int64_t)-1 : (int64_t)st->total[use_b];
     }
     if (threadIdx.x < 6 && out_aabb) {
         const int a = threadIdx.x;
@@ -834,6 +839,20 @@ extern "C" int pch_mean_seq_f32(const float* xyz, int64_t n, float* out_centroid
     ms_plan(a, n, w);
     if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
     return mean_seq_launch(xyz, n, out_centroid, w, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int pch_mean_seq_partial_f32(const float* xyz, int64_t n, const float* sum_in3, int64_t total_n,
+                                        float* out3, int32_t phase, void* ws, size_t ws_bytes, void* stream) {
+    PCH_DEVICE_GUARD(ws);
+    PCH_REQUIRE(n >= 0 && total_n >= 0 && ws && phase >= 0 && phase <= 2, "bad argument");
+    PCH_REQUIRE(phase == MS_PHASE_TABLES || out3, "null output");
+    PCH_REQUIRE(n == 0 || xyz, "null input");
+    Arena a(ws, ws_bytes, phase == MS_PHASE_WALK);       // the walk continues the tables of the call before
+    MsWs w;
+    ms_plan(a, n, w);
+    if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
+    return mean_seq_launch(xyz, n, out3, w, nullptr, (hipStream_t)stream, nullptr, sum_in3,
+                           total_n > 0 ? total_n : MS_NO_DIVIDE, phase);
 }
 
 extern "C" int pch_mean_seq_serial_f32(const float* xyz, int64_t n, float* out_centroid, void* stream) {
@@ -945,7 +964,7 @@ __global__ void gf_zcol_k(const float* __restrict__ raw, int64_t n, float* __res
     if (i < n) zcol[i] = raw[3 * i + 2];
 }
 __global__ void gf_count_out_k(const GfState* __restrict__ st, int64_t* __restrict__ out_count, float* __restrict__ out_aabb) {
-    if (threadIdx.x == 0) *out_count = (int64_t)st->total[0];
+    if (threadIdx.x == 0) *out_count = st->failed ? (int64_t)-1 : (int64_t)st->total[0];
     if (threadIdx.x < 6 && out_aabb) {
         const int a = threadIdx.x;
         uint32_t v = 0;

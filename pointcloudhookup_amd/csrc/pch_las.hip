@@ -86,7 +86,14 @@ static int las_parse(const char* path, const unsigned char* h, size_t size, PchL
                   (int)out->record_length, (int)out->point_format, need);
         return PCH_ERR_ARG;
     }
-    if ((uint64_t)out->offset_to_points + count * (uint64_t)out->record_length > size) {
+    if (out->offset_to_points < out->header_size) {
+        set_error("%s: offset to point data (%u) lies inside the %d-byte header", path, out->offset_to_points,
+                  (int)out->header_size);
+        return PCH_ERR_ARG;
+    }
+    // no multiplication: a forged 64-bit count must not wrap the product past the check
+    if ((uint64_t)out->offset_to_points > (uint64_t)size ||
+        count > ((uint64_t)size - (uint64_t)out->offset_to_points) / (uint64_t)out->record_length) {
         set_error("%s: truncated (%llu records of %d bytes from offset %u do not fit %zu bytes)", path,
                   (unsigned long long)count, (int)out->record_length, out->offset_to_points, size);
         return PCH_ERR_ARG;

@@ -595,12 +595,15 @@ __device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ x
 
 // one wave per column: walks the level-2 rows, descends into the children of a row only when
 // its certificate fails
+// sum_in (optional): the running sum this shard continues (a file-order shard of a larger array, see
+// pch_mean_seq_partial_f32); divide_n: 0 = store the running sum itself, else divide by float32(divide_n)
 __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, int64_t n, MsTables T,
+                                                const float* __restrict__ sum_in, int64_t divide_n, int divide,
                                                 float* __restrict__ out, int* __restrict__ stats) {
     __shared__ float stage[MSB + MSB / 16];
     const int c = blockIdx.x;
     const int l = lane_id();
-    uint32_t sb = 0;                                   // bits of the running sum (+0.0)
+    uint32_t sb = sum_in ? __float_as_uint(sum_in[c]) : 0u;      // bits of the running sum (+0.0 at the start)
     int64_t b = 0;                                     // next level-2 row
     int n_exact = 0, n_batches = 0, n_desc = 0;
     int serial_len = MS_SEG;
@@ -645,7 +648,8 @@ __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, i
         b += reload ? start : 64;
     }
     if (l == 0) {
-        out[c] = __uint_as_float(sb) / (float)n;       // n == 0 -> 0/0 = NaN like numpy
+        // n == 0 -> 0/0 = NaN like numpy
+        out[c] = divide ? __uint_as_float(sb) / (float)divide_n : __uint_as_float(sb);
         if (stats) {
             stats[4 * c + 0] = n_batches; stats[4 * c + 1] = 0;
             stats[4 * c + 2] = n_exact; stats[4 * c + 3] = n_desc;
@@ -692,20 +696,23 @@ void ms_plan(Arena& a, int64_t n, MsWs& w) {
 }
 
 int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zcol, hipStream_t s,
-                    hipEvent_t ev_zcol) {
+                    hipEvent_t ev_zcol, const float* sum_in, int64_t divide_n, int phase) {
     const int64_t nb = n > 0 ? ceil_div(n, MSB) : 0;
     const int64_t nb2 = ceil_div(nb, 64);
-    if (n > 0) {
+    if (n > 0 && phase != MS_PHASE_WALK) {
         PCH_LAUNCH("mean_summary", ms_summary_k, dim3((unsigned)ceil_div(nb, MS_WAVES)), dim3(64 * MS_WAVES),
                    0, s, xyz, n, nb, w.rec, zcol);
         if (ev_zcol) PCH_HIP_TRY(hipEventRecord(ev_zcol, s));
         PCH_LAUNCH("mean_level2", ms_level2_k, dim3((unsigned)(3 * nb2)), dim3(256), 0, s,
                    (const MsRec*)w.rec, nb, nb2, w.hdr2, w.rows2);
     }
+    if (phase == MS_PHASE_TABLES) return PCH_OK;
     MsTables T;
     T.rec = w.rec; T.nb = nb;
     T.hdr2 = w.hdr2; T.rows2 = w.rows2; T.nb2 = nb2;
-    PCH_LAUNCH("mean_walk", ms_walk_k, dim3(3), dim3(64), 0, s, xyz, n, T, out, w.stats);
+    const int divide = divide_n != MS_NO_DIVIDE;
+    PCH_LAUNCH("mean_walk", ms_walk_k, dim3(3), dim3(64), 0, s, xyz, n, T, sum_in,
+               divide_n == MS_DIVIDE_BY_N ? n : divide_n, divide, out, w.stats);
     return PCH_OK;
 }
 

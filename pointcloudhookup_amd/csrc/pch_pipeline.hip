@@ -74,6 +74,10 @@ extern "C" int pch_tower_clusters_f32(const float* raw, int64_t n, double pct, f
     memcpy(info_host->aabb, h.aabb, sizeof(h.aabb));
     info_host->count = h.count;
     const int64_t nf = h.count;
+    if (nf < 0) {                                        // gf_compact's look-back gave up (pch_lookback.h)
+        set_error("stage B: a device-side look-back wait ran out of its budget; outputs are undefined");
+        return PCH_ERR_TIMEOUT;
+    }
     if (nf > nf_cap) {
         set_error("the filter kept %lld points, more than nf_cap = %lld", (long long)nf, (long long)nf_cap);
         return PCH_ERR_WORKSPACE;

@@ -52,10 +52,16 @@ __global__ __launch_bounds__(CR_THREADS) void crop_aabb_k(const double* __restri
     __syncthreads();
     const uint32_t T = wtot[0] + wtot[1] + wtot[2] + wtot[3];
     if (w == 0) {
-        const uint32_t e = gf_lookback(status, tile, T);
+        const uint32_t e0 = gf_lookback(status, tile, T);
+        const bool lb_failed = e0 == GF_LB_FAILED;
+        const uint32_t e = lb_failed ? 0u : e0;              // prefix 0 keeps the writes below inside the output
         if (l == 0) {
             excl_sh = e;
-            if (tile == (int64_t)gridDim.x - 1) *out_count = (int64_t)e + T;
+            // out_count starts at 0: the last tile adds the total, a tile whose wait ran out of its budget adds
+            // -2^62 - the sum is negative iff some tile failed, in whatever order the two happen
+            unsigned long long* oc = reinterpret_cast<unsigned long long*>(out_count);
+            if (lb_failed) atomicAdd(oc, (unsigned long long)(-(1ll << 62)));
+            else if (tile == (int64_t)gridDim.x - 1) atomicAdd(oc, (unsigned long long)e + T);
         }
     }
     __syncthreads();
@@ -136,11 +142,52 @@ extern "C" int pch_crop_aabb_f64(const double* xyz, int64_t n, const double* min
     uint64_t* status = a.take<uint64_t>(nt);
     if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
     PCH_HIP_TRY(hipMemsetAsync(ws, 0, a.off, s));
+    PCH_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(int64_t), s));
     CropBox box;
     for (int k = 0; k < 3; ++k) { box.lo[k] = min3_host[k]; box.hi[k] = max3_host[k]; }
     PCH_LAUNCH("crop_aabb", crop_aabb_k, dim3((unsigned)nt), dim3(CR_THREADS), 0, s, xyz, n, box, st, status,
                out_points, out_index, out_count);
     return PCH_OK;
+}
+
+// ---- self-test of the bounded look-back wait (pch_lookback.h): four tiles in ticket order, the workgroup that
+// draws ticket 1 leaves WITHOUT publishing - what a lost or never-scheduled tile looks like to the tiles behind
+// it.  Tickets 2 and 3 must give up after `budget` ticks, poison their words and raise the failure word; the grid
+// drains by construction.  Never part of the data path.
+namespace pch {
+__global__ __launch_bounds__(64) void lb_selftest_k(uint64_t* __restrict__ status, uint32_t* __restrict__ state,
+                                                    unsigned long long budget) {
+    __shared__ uint32_t tile_sh;
+    if (threadIdx.x == 0) tile_sh = atomicAdd(&state[0], 1u);
+    __syncthreads();
+    const int64_t tile = tile_sh;
+    if (tile == 1) return;                               // the tile that never publishes
+    const uint32_t e = gf_lookback(status, tile, 1u, false, budget);
+    if (threadIdx.x == 0) {
+        if (e == GF_LB_FAILED) atomicAdd(&state[1], 1u);
+        else atomicAdd(&state[2], 1u);
+    }
+}
+}  // namespace pch
+
+extern "C" int pch_selftest_lookback_timeout(int budget_ms, void* dev_scratch, size_t scratch_bytes, void* stream) {
+    PCH_DEVICE_GUARD(dev_scratch);
+    hipStream_t s = (hipStream_t)stream;
+    PCH_REQUIRE(budget_ms >= 1 && budget_ms <= 2000 && dev_scratch && scratch_bytes >= 256, "bad argument");
+    uint64_t* status = static_cast<uint64_t*>(dev_scratch);
+    uint32_t* state = reinterpret_cast<uint32_t*>(status + 8);
+    PCH_HIP_TRY(hipMemsetAsync(dev_scratch, 0, 256, s));
+    PCH_LAUNCH("lb_selftest", lb_selftest_k, dim3(4), dim3(64), 0, s, status, state,
+               (unsigned long long)budget_ms * 100000ull);
+    uint32_t st[4];
+    PCH_TRY(peek_enqueue(state, sizeof(st), s));
+    PCH_TRY(peek_wait(st, sizeof(st)));
+    if (st[0] != 4 || st[1] != 2 || st[2] != 1) {        // ticket 0 succeeds, 1 leaves, 2 and 3 give up
+        set_error("look-back self-test: tickets %u, gave up %u, succeeded %u (expected 4 / 2 / 1)", st[0], st[1], st[2]);
+        return PCH_ERR_HIP;
+    }
+    set_error("look-back wait ran out of its %d ms budget (self-test: expected)", budget_ms);
+    return PCH_ERR_TIMEOUT;
 }
 
 extern "C" int pch_decimate_f64(const double* xyz, int64_t n, int64_t k, uint64_t seed, double* out_points,

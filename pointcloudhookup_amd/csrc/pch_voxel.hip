@@ -460,7 +460,7 @@ struct VfShared {
     uint32_t cnt[VF_WAVES][256];                 // per-wave digit counters / offsets (16 KB)
     uint32_t base[256];
     uint32_t wsum[VF_WAVES];
-    uint32_t ticket, vbase;
+    uint32_t ticket, vbase, lb_failed;
 };
 
 // block-wide exclusive scan of one value per thread (VF_THREADS threads); total returned to all
@@ -827,16 +827,23 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
         VX_STAMP(3);
         // ---- first output slot of this batch: look-back over the batches in front (ticket order)
         if (w == 0) {
-            const uint32_t e = gf_lookback(status, (int64_t)t, nvox, announced);
-            if (l == 0) sh.vbase = e;
+            const uint32_t e0 = gf_lookback(status, (int64_t)t, nvox, announced);
+            if (l == 0) {
+                sh.vbase = e0 == GF_LB_FAILED ? 0u : e0;     // slot 0 keeps the writes below inside the output
+                sh.lb_failed = e0 == GF_LB_FAILED ? 1u : 0u;
+            }
         }
         __syncthreads();
         const int64_t vbase = sh.vbase;
         VX_STAMP(4);
         if (tid == 0) {
+            // *out_m starts at 0: the last batch adds the total, a batch whose wait ran out of its budget adds
+            // -2^62 - the sum is negative iff some batch failed, in whatever order the two happen
+            unsigned long long* om = reinterpret_cast<unsigned long long*>(out_m);
+            if (sh.lb_failed) atomicAdd(om, (unsigned long long)(-(1ll << 62)));
             if (first_of_chunk && out_chunk_offsets) out_chunk_offsets[c] = vbase;
-            if (t == nbatches - 1) {
-                *out_m = vbase + nvox;
+            if (t == nbatches - 1 && !sh.lb_failed) {
+                atomicAdd(om, (unsigned long long)(vbase + nvox));
                 if (out_chunk_offsets) out_chunk_offsets[g.nchunks] = vbase + nvox;
             }
         }
@@ -947,6 +954,7 @@ extern "C" int pch_voxel_downsample_f64(const double* xyz, int64_t n, double vox
     PCH_HIP_TRY(hipMemsetAsync(w.mm, 0, sizeof(unsigned long long) * nchunks * 6, s));
     PCH_HIP_TRY(hipMemset2DAsync(w.mm, 48, 0xFF, 24, nchunks, s));
     PCH_HIP_TRY(hipMemsetAsync(w.gmeta, 0, sizeof(int) * 4, s));
+    PCH_HIP_TRY(hipMemsetAsync(out_m, 0, sizeof(int64_t), s));           // the finisher ADDS to it (see vx_finish_k)
     const int64_t bpc = ceil_div(chunk_size, VX_THREADS * VX_MM_ROUNDS);
     PCH_LAUNCH("voxel_minmax", vx_minmax_k, dim3((unsigned)(bpc * nchunks)), dim3(VX_THREADS), 0, s,
                xyz, n, chunk_size, bpc, w.mm);

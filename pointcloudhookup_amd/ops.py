@@ -92,7 +92,7 @@ def voxel_downsample(xyz, voxel_size, chunk_size=0):
         _lib.check(L.pch_voxel_downsample_f64(_ptr(xyz), n, float(voxel_size), cs, _ptr(idx), _ptr(mean),
                                               _ptr(count), _ptr(offs), _ptr(m_dev), _ptr(ws), ws.numel(),
                                               _stream()))
-        m = int(m_dev.item())
+        m = _lib.check_count(m_dev.item(), "voxel_downsample")
     return idx[:m], mean[:m], count[:m], offs
 
 
@@ -160,6 +160,41 @@ def mean_seq_f32(xyz, serial=False):
         ws = _workspace(nb, xyz.device)
         _lib.check(L.pch_mean_seq_f32(_ptr(xyz), xyz.shape[0], _ptr(out), _ptr(ws), ws.numel(), _stream()))
     return out
+
+
+def mean_seq_partial_f32(xyz, sum_in=None, total_n=0):
+    """One file-order shard of np.mean(., axis=0): continues the float32 running sums ``sum_in`` (float32 [3] device
+    tensor, None = +0.0) over the rows of ``xyz``.  total_n == 0: returns the running sums after the rows (hand them
+    to the next shard); total_n > 0: returns sums / float32(total_n), the centroid (last shard).  float32 [3]."""
+    sh = MeanShard(xyz)
+    return sh.walk(sum_in, total_n)
+
+
+class MeanShard:
+    """A file-order shard of the sequential float32 column sums, in two phases (pch_mean_seq_partial_f32): the
+    constructor builds the shard's summary tables (the passes over the rows; independent of what comes before the
+    shard, so every rank does this at once), ``walk`` then continues GIVEN running sums over them (the short serial
+    part that is chained from rank to rank).  The tables live in a workspace that belongs to this object."""
+
+    def __init__(self, xyz):
+        L = _lib.lib()
+        self.xyz = _need_cuda(xyz, torch.float32, "xyz").reshape(-1, 3)
+        self.n, self.device = self.xyz.shape[0], self.xyz.device
+        with torch.cuda.device(self.device):
+            self.workspace = torch.empty(int(L.pch_mean_seq_f32_ws_bytes(self.n)) + 256, dtype=torch.uint8,
+                                         device=self.device)
+            _lib.check(L.pch_mean_seq_partial_f32(_ptr(self.xyz), self.n, 0, 0, 0, 1, _ptr(self.workspace),
+                                                  self.workspace.numel(), _stream()))
+
+    def walk(self, sum_in=None, total_n=0):
+        L = _lib.lib()
+        if sum_in is not None:
+            sum_in = _need_cuda(sum_in, torch.float32, "sum_in").reshape(3)
+        out = torch.empty((3,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.pch_mean_seq_partial_f32(_ptr(self.xyz), self.n, _ptr(sum_in), int(total_n), _ptr(out), 2,
+                                                  _ptr(self.workspace), self.workspace.numel(), _stream()))
+        return out
 
 
 def percentile_f32(values, q_percent, sub=None):
@@ -231,7 +266,7 @@ def filter_gt(raw, centroid, threshold, want_index=True):
         ws = _workspace(L.pch_filter_gt_ws_bytes(n), dev)
         _lib.check(L.pch_filter_gt_f32(_ptr(raw), n, C.cast(cen, C.c_void_p), float(np.float32(threshold)), _ptr(out_points),
                                        _ptr(out_index), _ptr(cnt), _ptr(aabb), _ptr(ws), ws.numel(), _stream()))
-        m = int(cnt.item())
+        m = _lib.check_count(cnt.item(), "filter_gt")
     return dict(points=out_points[:m], index=None if out_index is None else out_index[:m], count=m,
                 aabb=aabb.cpu().numpy())
 
@@ -255,7 +290,7 @@ def ground_filter(raw, pct=25.0, offset=3.0, fallback_offset=1.0, min_keep=1000,
                                            scal.data_ptr() + 64, scal.data_ptr() + 32, _ptr(ws), ws.numel(),
                                            _stream()))
         host = scal.cpu().numpy()           # one D2H copy, synchronises the stream
-        nf = int(host[16:18].view("<i8")[0])
+        nf = _lib.check_count(host[16:18].view("<i8")[0], "ground_filter")
     return dict(points=out_points[:nf], index=None if out_index is None else out_index[:nf],
                 centroid=host[0:3].copy(), base=host[3], threshold=host[4],
                 used_fallback=bool(host[5] != 0.0), count_at_offset=int(host[6:7].view("<u4")[0]),
@@ -287,36 +322,64 @@ def dbscan(xyz, eps=8.0, min_samples=80, chunk_size=50000, aabb=None, want_core=
     return labels, core, k
 
 
-def dbscan_relabel(labels, cluster_map):
-    """Continues the LAST ops.dbscan call of this thread (its workspace still holds the grid): core
-    points take cluster_map[old id], border points are decided again as the smallest new id among
-    their core neighbours.  labels int32 [n] is updated in place and returned."""
-    L = _lib.lib()
-    labels = _need_cuda(labels, torch.int32, "labels")
-    cmap = _need_cuda(cluster_map, torch.int32, "cluster_map")
-    dev = labels.device
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    ws = getattr(_tls, "ws", {}).get(key)
-    if ws is None:
-        raise RuntimeError("dbscan_relabel must follow ops.dbscan on this thread")
-    with torch.cuda.device(dev):
-        _lib.check(L.pch_dbscan_relabel_i32(_ptr(cmap), cmap.numel(), labels.numel(), _ptr(labels), _ptr(ws),
-                                            ws.numel(), _stream()))
-    return labels
+class DbscanFit:
+    """One exact DBSCAN whose grid stays alive: labels, core flags and cluster count of ``ops.dbscan`` plus a
+    workspace that belongs to this fit alone, so that ``first_core_rows`` and ``relabel`` may follow after any
+    number of other ops (the shared per-thread scratch buffer of ``_workspace`` is never used here).  The library
+    remembers one fit per thread: a second fit on the same thread retires the first, and a retired fit's
+    continuation calls raise (PCH_ERR_ARG) instead of reading another run's grid."""
 
+    def __init__(self, xyz, eps=8.0, min_samples=80, chunk_size=0, aabb=None):
+        import ctypes as C
+        L = _lib.lib()
+        xyz = _need_cuda(xyz, torch.float32, "xyz").reshape(-1, 3)
+        n = xyz.shape[0]
+        dev = xyz.device
+        self.n, self.device = n, dev
+        with torch.cuda.device(dev):
+            self.labels = torch.empty((n,), dtype=torch.int32, device=dev)
+            self.core = torch.empty((n,), dtype=torch.uint8, device=dev)
+            ncl = torch.zeros((1,), dtype=torch.int32, device=dev)
+            self.workspace = torch.empty(int(L.pch_dbscan_ws_bytes(n)) + 256, dtype=torch.uint8, device=dev)
+            box = None if aabb is None else (C.c_float * 6)(*[float(v) for v in aabb])
+            _lib.check(L.pch_dbscan_f32(_ptr(xyz), n, float(eps), int(min_samples), int(chunk_size),
+                                        None if box is None else C.cast(box, C.c_void_p), _ptr(self.labels),
+                                        _ptr(self.core), _ptr(ncl), _ptr(self.workspace), self.workspace.numel(),
+                                        _stream()))
+            self.nclusters = int(ncl.item())
 
-def dbscan_first_core_rows(n, nclusters, device):
-    """Smallest core row of every cluster of the LAST ops.dbscan call of this thread (int32 [nclusters])."""
-    L = _lib.lib()
-    dev = torch.device(device)
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    ws = getattr(_tls, "ws", {}).get(key)
-    if ws is None:
-        raise RuntimeError("dbscan_first_core_rows must follow ops.dbscan on this thread")
-    out = torch.empty((int(nclusters),), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
-        _lib.check(L.pch_dbscan_first_core_rows_i32(int(n), _ptr(out), _ptr(ws), ws.numel(), _stream()))
-    return out
+    def first_core_rows(self):
+        """Smallest core row of every cluster (int32 [nclusters], ascending with the cluster id)."""
+        L = _lib.lib()
+        out = torch.empty((self.nclusters,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.pch_dbscan_first_core_rows_i32(self.n, _ptr(out), _ptr(self.workspace),
+                                                        self.workspace.numel(), _stream()))
+        return out
+
+    def strip_pairs(self, x_lo, x_hi, cap=4096):
+        """(int32 [cap,2] device buffer of (local row, cluster id) pairs, int32 [1] device count): one pair per grid
+        cell that holds a core point with x_lo <= x < x_hi (pch_dbscan_strip_pairs_i32).  Asynchronous: the count
+        is read by whoever needs it (it may exceed cap - then call again with a larger cap).  Before relabel."""
+        import numpy as np
+        L = _lib.lib()
+        pairs = torch.empty((int(cap), 2), dtype=torch.int32, device=self.device)
+        count = torch.empty((1,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.pch_dbscan_strip_pairs_i32(self.n, float(np.float32(x_lo)), float(np.float32(x_hi)), int(cap),
+                                                    _ptr(pairs), _ptr(count), _ptr(self.workspace),
+                                                    self.workspace.numel(), _stream()))
+        return pairs, count
+
+    def relabel(self, cluster_map):
+        """Core points take cluster_map[old id], border points are decided again as the smallest new id among
+        their core neighbours.  ``labels`` is updated in place and returned."""
+        L = _lib.lib()
+        cmap = _need_cuda(cluster_map, torch.int32, "cluster_map")
+        with torch.cuda.device(self.device):
+            _lib.check(L.pch_dbscan_relabel_i32(_ptr(cmap), cmap.numel(), self.n, _ptr(self.labels),
+                                                _ptr(self.workspace), self.workspace.numel(), _stream()))
+        return self.labels
 
 
 def set_dbscan_sort_mode(mode):
@@ -493,7 +556,7 @@ def crop_aabb(xyz, lo, hi, want_index=False):
         ws = _workspace(L.pch_crop_aabb_ws_bytes(n), dev)
         _lib.check(L.pch_crop_aabb_f64(_ptr(xyz), n, C.cast(mn, C.c_void_p), C.cast(mx, C.c_void_p), _ptr(out),
                                        _ptr(idx), _ptr(cnt), _ptr(ws), ws.numel(), _stream()))
-        m = int(cnt.item())
+        m = _lib.check_count(cnt.item(), "crop_aabb")
     return (out[:m], idx[:m]) if want_index else out[:m]
 
 

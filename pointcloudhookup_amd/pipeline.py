@@ -130,48 +130,3 @@ def tower_table(clusters, aspect_ratio_threshold=0.8, min_height=15.0, max_width
         if on_accept:
             on_accept(item)
     return towers
-    centroid = gf["centroid"]                                   # float32[3]
-    offsets = clusters["offsets"].cpu().numpy()
-    perm = clusters["perm"]
-    pts = gf["points"]
-    # one gather + one D2H copy for all clustered points (noise rows stay on the device)
-    rows = perm[: int(offsets[k])].long()
-    host_pts = pts.index_select(0, rows).cpu().numpy()
-    parts = [host_pts[offsets[label]:offsets[label + 1]] for label in range(k)]
-    # boxes of all clusters (PCH_OBB_WORKERS > 1: worker processes), consumed in label order
-    for label, (box, err) in enumerate(_obb.boxes_of(parts, extent_order)):
-        try:
-            cluster_points = parts[label]
-            if err is not None:
-                raise err
-            extents, transform = box
-            height = extents[2]
-            width = max(extents[0], extents[1])
-            aspect_ratio = height / width
-            if not (height > min_height and min_width < width < max_width
-                    and aspect_ratio > aspect_ratio_threshold):
-                continue
-            obb_center = transform[:3, 3] + centroid
-            dup = None
-            for c in centers:
-                d = np.linalg.norm(obb_center - c)
-                if d < duplicate_threshold:
-                    dup = d
-                    break
-            if dup is not None:
-                if log:
-                    log(f"⚠️ 跳过重复杆塔{label} (中心距: {dup:.1f}m)")
-                continue
-            rot = transform[:3, :3]
-            tower = dict(label=label, center=obb_center, rotation=rot, extent=extents,
-                         height=height, width=width, aspect_ratio=aspect_ratio,
-                         north_angle=north_angle_deg(rot), points=cluster_points)
-            towers.append(tower)
-            centers.append(obb_center)
-            if on_accept:
-                on_accept(tower)
-        except Exception as e:                                  # utils/tower_extraction.py:213-215
-            if log:
-                log(f"⚠️ 簇{label} 处理失败: {str(e)}")
-            continue
-    return towers

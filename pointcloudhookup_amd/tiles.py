@@ -19,7 +19,7 @@ rank, every tile extended by a 2*eps halo, clustered globally (no 50 000-row chu
 by a tile edge must come out as ONE cluster with the id a single-GPU run over the whole cloud
 gives it: ``cluster_tiled`` below - local exact DBSCAN per tile, one all_gather of the
 (global row, local cluster) pairs of the core points near the tile edges, the same union-find on
-every rank, then a relabel pass on the device (``ops.dbscan_relabel``) that also re-decides the
+every rank, then a relabel pass on the device (``ops.DbscanFit.relabel``) that also re-decides the
 border points under the new numbering.
 """
 from __future__ import annotations
@@ -31,8 +31,9 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, timeout_s=None):
     """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* when WORLD_SIZE > 1.
+    ``timeout_s`` bounds every collective (a rank that died leaves the others waiting at most that long).
     Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -42,7 +43,11 @@ def init_from_env(backend=None):
             backend = os.environ.get("PCH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if timeout_s:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
@@ -151,44 +156,86 @@ def tile_select(x, edges, rank, halo):
 
 
 class HipFit:
-    """Local clustering on the GPU: exact global DBSCAN of one tile + relabelling on the retained grid."""
+    """Local clustering on the GPU: exact global DBSCAN of one tile + relabelling on the retained grid
+    (ops.DbscanFit: the grid lives in a workspace of its own, whatever runs between fit and relabel)."""
 
     def __init__(self, eps, min_samples):
         self.eps, self.min_samples = float(eps), int(min_samples)
-        self.labels = None
+        self._fit = None
 
     def fit(self, points):
         from . import ops
-        self.labels, core, k = ops.dbscan(points, self.eps, self.min_samples, 0, want_core=True)
-        return self.labels, core.bool(), k
+        self._fit = ops.DbscanFit(points, self.eps, self.min_samples, 0)
+        return self._fit.labels, self._fit.core.bool(), self._fit.nclusters
 
     def first_core_rows(self, k):
         """local row of the first core point of every cluster (what numbers the clusters)"""
-        from . import ops
-        return ops.dbscan_first_core_rows(self.labels.numel(), k, self.labels.device).long()
+        return self._fit.first_core_rows().long()
+
+    def strip_pairs(self, x_lo, x_hi, cap):
+        """((local row, local cluster) int32 [cap,2], count int32 [1]) - one pair per grid cell with a core point
+        in the strip (pch_dbscan_strip_pairs_i32)"""
+        return self._fit.strip_pairs(x_lo, x_hi, cap)
 
     def relabel(self, cluster_map):
-        from . import ops
-        cmap = torch.as_tensor(cluster_map, dtype=torch.int32, device=self.labels.device)
-        return ops.dbscan_relabel(self.labels, cmap)
+        cmap = torch.as_tensor(cluster_map, dtype=torch.int32, device=self._fit.device)
+        return self._fit.relabel(cmap)
 
 
-def _gather_rows(t, group):
-    """all_gather of a [k, C] int64 tensor whose k differs per rank.  Returns list of per-rank tensors."""
+# capacities of the two fixed-size exchanges of cluster_tiled (per rank): clusters, strip pairs, links.  A rank that
+# holds more is seen by everybody in the block's header and ONE exactly sized exchange follows (same branch on all)
+TILED_KCAP, TILED_PCAP, TILED_LCAP = 2048, 4096, 1024
+
+
+def _all_gather_block(block, group):
+    """ONE collective: every rank's equally sized 1-D block -> [world, len] tensor on the block's device."""
     world = dist.get_world_size(group)
-    cnt = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
-    counts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(counts, cnt, group=group)
-    counts = [int(c.item()) for c in counts]
-    kmax = max(max(counts), 1)
-    padded = torch.zeros((kmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    padded[: t.shape[0]] = t
-    out = [torch.zeros_like(padded) for _ in range(world)]
-    dist.all_gather(out, padded, group=group)
-    return [o[:c] for o, c in zip(out, counts)]
+    out = torch.empty((world * block.numel(),), dtype=block.dtype, device=block.device)
+    try:
+        dist.all_gather_into_tensor(out, block, group=group)
+    except (RuntimeError, AttributeError, NotImplementedError):     # a backend without the flat form
+        parts = [torch.empty_like(block) for _ in range(world)]
+        dist.all_gather(parts, block, group=group)
+        out = torch.cat(parts)
+    return out.reshape(world, block.numel())
 
 
-def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fit=None, group=None):
+def _exchange(header, payloads, caps, comm_dev, group):
+    """All-gathers, in ONE collective, a block per rank = [len(payloads) counts | payload 0 padded to caps[0] | ...].
+    payloads: 1-D int64 tensors; header: their true lengths (ints, or 0-d device tensors that are never read on
+    this side).  If some rank's length exceeds its capacity, one more exchange sized by the largest lengths follows.
+    Returns (per-rank lists of numpy arrays, largest length of every payload over the ranks)."""
+    def pack(caps_now):
+        blk = torch.zeros((len(payloads) + sum(caps_now),), dtype=torch.int64, device=payloads[0].device)
+        at = len(payloads)
+        for j, (p, c) in enumerate(zip(payloads, caps_now)):
+            blk[j] = header[j] if torch.is_tensor(header[j]) else int(header[j])
+            m = min(int(p.numel()), c)
+            if m:
+                blk[at:at + m] = p[:m]
+            at += c
+        return blk
+
+    def unpack(out, caps_now):
+        res = []
+        for r in range(out.shape[0]):
+            row, at, parts = out[r], len(payloads), []
+            for j, c in enumerate(caps_now):
+                parts.append(row[at:at + min(int(row[j]), c)])
+                at += c
+            res.append(parts)
+        return res
+
+    caps = list(caps)
+    out = _all_gather_block(pack(caps).to(comm_dev), group).cpu().numpy()
+    need = out[:, :len(payloads)].max(axis=0)
+    if (need > np.asarray(caps)).any():                  # rare: a rank overflowed its block; everybody sees it
+        caps = [int(max(c, n)) for c, n in zip(caps, need)]
+        out = _all_gather_block(pack(caps).to(comm_dev), group).cpu().numpy()
+    return unpack(out, caps), [int(v) for v in need]
+
+
+def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fit=None, group=None, timings=None):
     """Global DBSCAN of a cloud that is spread over the ranks as x-tiles with a halo of at least 2*eps.
 
     points : [n,3] float32 points of THIS rank's tile, halo included (device tensor for the HIP fit)
@@ -197,6 +244,7 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
     own    : [n] bool, True for the points this rank reports (x inside its own tile)
     x_lo, x_hi : this rank's own x-range [x_lo, x_hi)
     halo   : width of the overlap on either side (default and minimum 2*eps); every rank must use the same
+    timings: optional dict; "fit_ms" / "reconcile_ms" are ADDED to it (wall clock, the device drained in between)
     Returns (labels int32 [n] for ALL local points (valid where ``own``), number of global clusters).
 
     Result for the owned points = one DBSCAN(eps, min_samples) over the whole cloud, ids = rank of the
@@ -205,34 +253,52 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
     outer ring can only be false negatives.  So local clusters are sound pieces of the true clusters, every
     true core-core edge is seen whole by the tile that owns one endpoint, and pieces that share a core
     point (same global row, seen by two tiles) belong together.  Border points are re-decided after the
-    renumbering on the device (their core neighbours all have exact flags)."""
+    renumbering on the device (their core neighbours all have exact flags).
+
+    The exchange: TWO collectives per call, each ONE all_gather of a fixed-capacity block per rank
+    whose header carries the true counts - (1) the smallest global core row of every local cluster + the
+    (global row, local cluster) pairs of the strip at the tile's upper edge, one pair per grid cell
+    (pch_dbscan_strip_pairs_i32); (2) the piece-to-piece links the right-hand tile found by looking those rows up in
+    its own labels.  The same union (scipy connected_components) then runs on every rank."""
+    import time
+    t_start = time.perf_counter()
     fit = fit or HipFit(eps, min_samples)
     labels, core, k = fit.fit(points)
     k = int(k)
+    t_fit = time.perf_counter()                            # fit() has read the cluster count: the device is drained
     single = not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1
     # bookkeeping stays where the points are (device tensors with the HIP fit): only the per-cluster table and
-    # the pairs of the core points near the tile edges ever leave the device
+    # the pairs of the strip cells ever leave the device
     pts_t = torch.as_tensor(points)
     wdev = pts_t.device
     rows_d = torch.as_tensor(rows).to(wdev, torch.int64)
     lab_d = torch.as_tensor(labels).to(wdev, torch.int64)
     core_d = torch.as_tensor(core).to(wdev).bool()
-    x_d = pts_t[:, 0]
     # smallest global core row of every local cluster.  `rows` ascends with the local row, so it is the global
     # row of the cluster's first local core point - which the fit knows (it numbers the clusters by it)
     cm = core_d & (lab_d >= 0)
     if hasattr(fit, "first_core_rows"):
-        minrow = rows_d[fit.first_core_rows(k)].cpu() if k else torch.zeros(0, dtype=torch.int64)
+        minrow = rows_d[fit.first_core_rows(k)] if k else torch.zeros(0, dtype=torch.int64, device=wdev)
     else:
         minrow = torch.full((max(k, 1),), torch.iinfo(torch.int64).max, dtype=torch.int64, device=wdev)
         if k:
             minrow.scatter_reduce_(0, lab_d[cm], rows_d[cm], reduce="amin")
-        minrow = minrow[:k].cpu()
+        minrow = minrow[:k]
+
+    def done(labels_out, total):
+        if timings is not None:
+            if torch.as_tensor(labels_out).is_cuda:
+                torch.cuda.synchronize(wdev)
+            t_end = time.perf_counter()
+            timings["fit_ms"] = timings.get("fit_ms", 0.0) + 1e3 * (t_fit - t_start)
+            timings["reconcile_ms"] = timings.get("reconcile_ms", 0.0) + 1e3 * (t_end - t_fit)
+        return labels_out, total
+
     if single:
         order = torch.argsort(minrow)
-        cmap = torch.empty(k, dtype=torch.int64)
-        cmap[order] = torch.arange(k)
-        return fit.relabel(cmap.to(torch.int32)), k
+        cmap = torch.empty(k, dtype=torch.int64, device=wdev)
+        cmap[order] = torch.arange(k, device=wdev)
+        return done(fit.relabel(cmap.to(torch.int32)), k)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     comm_dev = torch.device("cpu")
     if dist.get_backend(group) == "nccl":                 # RCCL moves device buffers (a few KB..MB over xGMI)
@@ -244,53 +310,58 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
         raise ValueError("a tile must be at least one halo wide (only neighbouring tiles are matched)")
     # Which pieces belong together?  Every true core-core edge that crosses the tile edge e has an endpoint within
     # eps of e, and such a point has its exact core flag in BOTH tiles.  So it is enough that the left tile of every
-    # edge publishes the (global row, local cluster) pairs of its core points with x in [e - eps, e + eps); the right
-    # tile looks those rows up in its own labels (on the device) and reports the distinct (left piece, right piece)
-    # links - a handful of pairs, whatever the number of shared points.
+    # edge publishes (global row, local cluster) for its core points with x in [e - eps, e + eps) - one per grid
+    # cell, since the core points of a cell are one cluster in either tile; the right tile looks those rows up in
+    # its own labels (on the device) and reports the distinct (left piece, right piece) links.
     e_hi = float(x_hi)
-    strip = cm & (x_d >= e_hi - float(eps)) & (x_d < e_hi + float(eps))
-    if rank == world - 1:
-        strip = strip & False                              # no tile to the right
-    pairs = torch.stack([rows_d[strip], lab_d[strip]], dim=1)        # (global row, LOCAL cluster id)
-    all_minrow = _gather_rows(minrow.reshape(-1, 1).to(comm_dev), group)
-    all_pairs = _gather_rows(pairs.to(comm_dev), group)
-    counts = [int(m.shape[0]) for m in all_minrow]
+    pcap = TILED_PCAP
+    while True:
+        if rank == world - 1:                              # no tile to the right
+            pairs, npairs2 = torch.zeros((0,), dtype=torch.int64, device=wdev), 0
+        elif hasattr(fit, "strip_pairs"):
+            loc, cnt = fit.strip_pairs(e_hi - float(eps), e_hi + float(eps), pcap)
+            npairs2 = 2 * cnt.reshape(-1)[0].to(torch.int64)     # stays on the device: it travels in the header
+            n_here = int(rows_d.numel())
+            grow = (rows_d[loc[:, 0].long().clamp_(0, max(n_here - 1, 0))] if n_here
+                    else torch.zeros(pcap, dtype=torch.int64, device=wdev))
+            pairs = torch.stack([grow, loc[:, 1].long()], dim=1).reshape(-1)
+        else:
+            x_d = pts_t[:, 0]
+            strip = cm & (x_d >= e_hi - float(eps)) & (x_d < e_hi + float(eps))
+            pairs = torch.stack([rows_d[strip], lab_d[strip]], dim=1).reshape(-1)   # (global row, LOCAL cluster id)
+            npairs2 = int(pairs.numel())
+        got, need = _exchange([k, npairs2], [minrow, pairs], [TILED_KCAP, 2 * pcap], comm_dev, group)
+        if not hasattr(fit, "strip_pairs") or need[1] <= 2 * pcap:
+            break
+        pcap = need[1] // 2                                # some strip has more cells than the pair buffer: once more
+    counts = [int(g[0].shape[0]) for g in got]
     offs = np.concatenate([[0], np.cumsum(counts)])
     total = int(offs[-1])
     links = torch.zeros((0, 2), dtype=torch.int64, device=wdev)
-    if rank > 0 and all_pairs[rank - 1].shape[0] and rows_d.numel():
-        theirs = all_pairs[rank - 1].to(wdev)             # the left neighbour's strip at my lower edge
-        at = torch.searchsorted(rows_d, theirs[:, 0]).clamp(max=rows_d.numel() - 1)      # rows ascend
+    if rank > 0 and got[rank - 1][1].shape[0] and rows_d.numel():
+        theirs = torch.from_numpy(np.ascontiguousarray(got[rank - 1][1]).reshape(-1, 2)).to(wdev)
+        at = torch.searchsorted(rows_d, theirs[:, 0].contiguous()).clamp(max=rows_d.numel() - 1)      # rows ascend
         hit = (rows_d[at] == theirs[:, 0]) & cm[at]
         if hit.any():
             links = torch.unique(torch.stack([theirs[hit, 1] + int(offs[rank - 1]), lab_d[at[hit]] + int(offs[rank])],
                                              dim=1), dim=0)
-    all_links = _gather_rows(links.to(comm_dev), group)
+    got2, _ = _exchange([2 * int(links.shape[0])], [links.reshape(-1)], [2 * TILED_LCAP], comm_dev, group)
     if total == 0:
-        return fit.relabel(torch.zeros(0, dtype=torch.int32)), 0
-    # union-find over all local clusters (uid = rank offset + local id)
-    parent = np.arange(total)
-
-    def find(a):
-        while parent[a] != a:
-            parent[a] = parent[parent[a]]
-            a = parent[a]
-        return a
-
-    for u, v in torch.cat(all_links).cpu().numpy().reshape(-1, 2):
-        a, b2 = find(int(u)), find(int(v))
-        if a != b2:
-            parent[max(a, b2)] = min(a, b2)
-    root = np.array([find(i) for i in range(total)])
-    mr = torch.cat([m.reshape(-1) for m in all_minrow]).cpu().numpy()
-    comp_min = np.full(total, np.iinfo(np.int64).max)
-    np.minimum.at(comp_min, root, mr)
-    roots = np.flatnonzero(root == np.arange(total))
-    roots = roots[np.argsort(comp_min[roots], kind="stable")]          # numbered by smallest core row
-    gid = np.full(total, -1, np.int64)
-    gid[roots] = np.arange(len(roots))
-    cmap = gid[root[offs[rank]:offs[rank] + k]]
-    return fit.relabel(torch.as_tensor(cmap, dtype=torch.int32)), int(len(roots))
+        return done(fit.relabel(torch.zeros(0, dtype=torch.int32)), 0)
+    # union over all local clusters (uid = rank offset + local id): components of the link graph, numbered by the
+    # smallest global core row of their pieces (sklearn's numbering of the whole cloud)
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    lk = np.concatenate([g[0] for g in got2]).reshape(-1, 2)
+    graph = coo_matrix((np.ones(len(lk), np.int8), (lk[:, 0], lk[:, 1])), shape=(total, total))
+    ncomp, comp = connected_components(graph, directed=False)
+    mr = np.concatenate([g[0] for g in got])
+    comp_min = np.full(ncomp, np.iinfo(np.int64).max)
+    np.minimum.at(comp_min, comp, mr)
+    gid_of_comp = np.empty(ncomp, np.int64)
+    gid_of_comp[np.argsort(comp_min, kind="stable")] = np.arange(ncomp)
+    cmap = gid_of_comp[comp[offs[rank]:offs[rank] + k]]
+    return done(fit.relabel(torch.as_tensor(cmap, dtype=torch.int32)), int(ncomp))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -342,28 +413,30 @@ def shared_percentile(values, q_percent, sub=None, select=None, group=None):
         return int(t.item())
 
     n_local = int(torch.as_tensor(values).shape[0])
-    N = int(allsum([n_local])[0])
-    if N == 0:
-        raise IndexError("index -1 is out of bounds for axis 0 with size 0")     # what np.percentile raises
-    # numpy's index arithmetic in float32 (numpy/lib/_function_base_impl.py, method 'linear' under NEP 50)
-    qf = np.float32(q_percent) / np.float32(100.0)
-    vi = np.float32(N - 1) * qf
-    prev = np.floor(vi)
-    gamma = np.float32(vi - prev)
+    rank = prefix = nan_total = cnt_final = N = 0
     same = False
-    if vi >= np.float32(N - 1):
-        prev, same = np.float32(N - 1), True
-    if vi < 0:
-        prev, same = np.float32(0), True
-    k0 = min(max(int(prev), 0), N - 1)
-    same = same or k0 == N - 1
-    rank, prefix, nan_total = k0, 0, 0
-    cnt_final = 0
     for p in range(3):
         h, nan = select.hist(values, p, prefix)
-        h = allsum(h)
         if p == 0:
-            nan_total = int(allsum([nan])[0])
+            # the first exchange also carries every rank's value count and NaN count: one all-reduce, not three
+            hx = allsum(np.concatenate([np.asarray(h, dtype=np.int64), [int(nan), n_local]]))
+            h, nan_total, N = hx[:-2], int(hx[-2]), int(hx[-1])
+            if N == 0:
+                raise IndexError("index -1 is out of bounds for axis 0 with size 0")     # what np.percentile raises
+            # numpy's index arithmetic in float32 (numpy/lib/_function_base_impl.py, method 'linear' under NEP 50)
+            qf = np.float32(q_percent) / np.float32(100.0)
+            vi = np.float32(N - 1) * qf
+            prev = np.floor(vi)
+            gamma = np.float32(vi - prev)
+            if vi >= np.float32(N - 1):
+                prev, same = np.float32(N - 1), True
+            if vi < 0:
+                prev, same = np.float32(0), True
+            k0 = min(max(int(prev), 0), N - 1)
+            same = same or k0 == N - 1
+            rank = k0
+        else:
+            h = allsum(h)
         nb = 256 if p == 2 else 4096
         cum = np.cumsum(h[:nb])
         b = int(np.searchsorted(cum, rank, side="right"))
@@ -385,3 +458,117 @@ def shared_percentile(values, q_percent, sub=None, select=None, group=None):
     if nan_total:
         r = np.float32(np.nan)
     return r
+
+
+# ------------------------------------------------------------------------------------------------
+# np.mean(raw, axis=0) over rows that are spread over the ranks as consecutive file-order shards
+class HipMeanShard:
+    """the per-rank part of the chained float32 column sums on the GPU (ops.MeanShard: tables first, walk later)"""
+
+    def __init__(self, rows):
+        from . import ops
+        self._sh = ops.MeanShard(rows)
+        self.device = self._sh.device
+
+    def walk(self, sum_in, total_n):
+        return self._sh.walk(sum_in, total_n)
+
+
+def sharded_centroid(own_rows, total_n, shard=None, group=None):
+    """np.mean(concatenation of every rank's rows in RANK order, axis=0) of float32 [n_r,3] shards, bit for bit:
+    numpy's sum is sequential per column, so the three running float32 sums travel down the line of ranks
+    (12 bytes per hop, one send/recv each) and the last rank divides by float32(total_n) and broadcasts.  Every rank
+    builds the summary tables of its own rows first and at the same time (they do not depend on the incoming
+    sums); only the short serial walks are chained.  Replaces utils/tower_extraction.py:63 for a cloud whose
+    file-order shards live on different GPUs.  Returns np.float32 [3] (host)."""
+    if int(total_n) == 0:                                  # np.mean of an empty array: 0 / 0 (every rank knows total_n)
+        return np.full(3, np.nan, dtype=np.float32)
+    shard = shard or HipMeanShard(own_rows)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not multi:
+        return torch.as_tensor(shard.walk(None, int(total_n))).cpu().numpy().astype(np.float32)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    wdev = getattr(shard, "device", torch.device("cpu"))
+    comm_dev = wdev if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    sum_in = None
+    if rank > 0:
+        buf = torch.empty(3, dtype=torch.float32, device=comm_dev)
+        dist.recv(buf, src=dist.get_global_rank(group, rank - 1) if group is not None else rank - 1, group=group)
+        sum_in = buf.to(wdev)
+    last = rank == world - 1
+    out = torch.as_tensor(shard.walk(sum_in, int(total_n) if last else 0)).to(comm_dev, torch.float32)
+    if not last:
+        dist.send(out, dst=dist.get_global_rank(group, rank + 1) if group is not None else rank + 1, group=group)
+        out = torch.empty(3, dtype=torch.float32, device=comm_dev)
+    src = dist.get_global_rank(group, world - 1) if group is not None else world - 1
+    dist.broadcast(out, src=src, group=group)
+    return out.cpu().numpy().astype(np.float32)
+
+
+def global_rows(local_row, n_own, group=None):
+    """Global row numbers of a tile whose rows are numbered relative to its first OWNED row: the owned blocks follow
+    each other in rank order, so the base is the exclusive prefix of n_own over the ranks (one all_gather of one
+    integer per rank - what reading the LAS headers of a tile stream gives).  Returns (rows int64, total rows)."""
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not multi:
+        return local_row, int(n_own)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = local_row.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    mine = torch.tensor([int(n_own)], dtype=torch.int64, device=dev)
+    out = _all_gather_block(mine, group).reshape(-1).cpu().tolist()
+    return local_row + int(sum(out[:rank])), int(sum(out))
+
+
+def tiled_step(tile, tile_rows, own, total_n, x_lo, x_hi, eps=8.0, min_samples=80, pct=25.0, offset=3.0,
+               fallback_offset=1.0, min_keep=1000, halo=None, group=None, timings=None):
+    """Stages B + C of the hot path over ONE cloud that is spread over the ranks (BASELINE config 4): every rank
+    holds a consecutive file-order shard that is also an x-tile, extended by a halo of at least 2*eps.
+
+    tile      : float32 [n_t,3] device tensor, this rank's rows (halo included) in file order
+    tile_rows : int64 [n_t] global row of every tile row, ascending
+    own       : bool [n_t], the rows this rank owns; over the ranks the owned rows are the consecutive blocks
+                [base_r, base_r + n_r) of the cloud, in rank order
+    total_n   : rows of the whole cloud
+    x_lo, x_hi: this rank's own x-range in the RAW frame (the tile edges)
+    Returns dict(centroid f32[3], threshold f32, used_fallback, points (kept, centred, halo included), rows (global),
+    own (bool per kept point), labels int32 (valid where own), nclusters (global)).
+
+      centroid   tiles.sharded_centroid over the owned rows       utils/tower_extraction.py:63
+      threshold  tiles.shared_percentile over the owned z + 3.0   :82-83 (fallback + 1.0 below 1000 survivors, :87-89)
+      filter     ops.filter_gt on tile + halo with those values    :64,84
+      cluster    tiles.cluster_tiled (global DBSCAN, no 50 000-row chunks: north star / SURVEY 8e-ii)
+    """
+    import time
+    from . import ops
+    t0 = time.perf_counter()
+    own_idx = torch.nonzero(own).flatten()
+    own_rows = tile[own_idx] if own_idx.numel() != tile.shape[0] else tile
+    centroid = sharded_centroid(own_rows.contiguous(), total_n, group=group)
+    base = shared_percentile(own_rows[:, 2], pct, sub=centroid[2], group=group)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def filtered(off):
+        thr = np.float32(base + np.float32(off))
+        kept = ops.filter_gt(tile, centroid, thr, want_index=True)
+        loc = kept["index"].long()
+        own_k = own[loc]
+        cnt = torch.tensor([int(own_k.sum())], dtype=torch.int64)
+        if multi:
+            if dist.get_backend(group) == "nccl":
+                cnt = cnt.to(tile.device)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+        return thr, kept, loc, own_k, int(cnt.item())
+
+    thr, kept, loc, own_k, survivors = filtered(offset)
+    used_fallback = False
+    if survivors < int(min_keep):                          # utils/tower_extraction.py:87-89, on the WHOLE cloud's count
+        thr, kept, loc, own_k, survivors = filtered(fallback_offset)
+        used_fallback = True
+    t1 = time.perf_counter()
+    cx = float(centroid[0])                                # the kept points are centred: so are the edges
+    labels, K = cluster_tiled(kept["points"], tile_rows[loc], own_k, float(x_lo) - cx, float(x_hi) - cx, eps,
+                              min_samples, halo=halo, group=group, timings=timings)
+    if timings is not None:
+        timings["filter_ms"] = timings.get("filter_ms", 0.0) + 1e3 * (t1 - t0)
+    return dict(centroid=centroid, threshold=thr, used_fallback=used_fallback, points=kept["points"],
+                rows=tile_rows[loc], own=own_k, labels=labels, nclusters=int(K), survivors=survivors)

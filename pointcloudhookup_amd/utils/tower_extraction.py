@@ -4,7 +4,10 @@ Same module-level names, keyword defaults, return value, log texts, progress mil
 side-effect files as /root/reference/utils/tower_extraction.py:20-285; the arithmetic runs on
 the GPU through libpch_hip.so (height filter, chunked DBSCAN, label grouping) with only the
 per-cluster box fit, LAS/xlsx writing and the Python bookkeeping on the host.  Like the
-reference this function never raises: failures are logged and what exists is returned.
+reference, read / filter / per-cluster failures are logged and what exists is returned; the ONE
+raising path is the reference's own (see ``CHUNK_FAILURE`` below): with the default
+``CHUNK_FAILURE = "reference"`` a chunk that scikit-learn would reject makes extract_towers raise
+UnboundLocalError exactly as the reference does; with "noise" the function never raises.
 
 Module knobs (not in the reference): ``OBB_EXTENT_ORDER`` ("unsorted" | "trimesh_sorted",
 env PCH_OBB_EXTENT_ORDER) selects the extent convention of the box fit, ``DEVICE`` the GPU,

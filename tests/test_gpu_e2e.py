@@ -234,19 +234,159 @@ def test_cluster_tiled_hip_equals_global_dbscan(cuda, oracle_clib, tmp_path, wor
     _run_tiled(tmp_path, world, "gpu", 29751 + world)
 
 
+@pytest.mark.parametrize("world", [1, 3])
+def test_sharded_centroid_hip(cuda, tmp_path, world):
+    """tests/test_host.py's sharded-centroid cases with pch_mean_seq_partial_f32 doing every rank's tables and walk
+    (tiles.HipMeanShard), `world` processes sharing this GPU, the 12-byte hops over gloo."""
+    from test_host import _run_mean
+    _run_mean(tmp_path, world, "gpu", 29811 + world)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_bench_tiled_mode_equals_the_single_gpu_run(cuda, world):
+    """BASELINE config 4 end to end through bench.py's own launcher: `python bench.py --gpus W --mode tiled --verify`
+    starts W ranks (sharing this one GPU, exchange over gloo - RCCL refuses two ranks on one device), every rank
+    generates ONLY its x-tile + halo of a 12 M-point strip corridor at EPSG scale, and tiles.tiled_step (chained
+    float32 centroid, percentile across the ranks, per-tile filter, global DBSCAN per tile, two fixed-capacity
+    all_gathers, relabel) must reproduce the single-GPU run of the whole cloud: centroid and threshold bit for bit,
+    every owned label, every kept row owned exactly once.  Towers sit on the strip edges, hence on the tile edges."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PCH_BENCH_SINGLE_DEVICE="1", PCH_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--mode", "tiled",
+                        "--points", "12000000", "--steps", "2", "--warmup", "1", "--verify"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    t = out["tiled"]
+    assert t["verified_against_single_gpu_run"] is True
+    assert t["ranks_seen"] == world and out["n_gpus"] == world and t["points_total"] == 12_000_000
+    assert t["clusters"] >= 3 and t["kept_points"] > 100_000
+    assert set(t["phase_ms_max_over_ranks"]) == {"centroid_chain+threshold+filter", "local_fit", "reconciliation"}
+
+
+def test_dbscan_strip_pairs_cover_every_strip_core_point(cuda):
+    """pch_dbscan_strip_pairs_i32: one (row, cluster) pair per grid cell with a core point in the strip.  Every core
+    point of the strip must be within eps of the representative of ITS cluster's pairs (same cell => within eps), the
+    representatives are core points of the strip carrying their own cluster id, and a short buffer reports the
+    full count."""
+    X = synth.corridor_torch(2_000_000, seed=synth.SEED0 + 41, kind="corridor", offset=False, device=cuda,
+                             dtype=torch.float32)
+    X = X[X[:, 2] > 3.0].contiguous()
+    fit = ops.DbscanFit(X, 8.0, 80, 0)
+    assert fit.nclusters >= 3
+    cx = float(X[fit.labels == 0][:, 0].mean())                       # a strip through the middle of a tower
+    lo, hi = np.float32(cx - 8.0), np.float32(cx + 8.0)
+    pairs, cnt = fit.strip_pairs(lo, hi, 4096)
+    m = int(cnt.item())
+    assert 0 < m <= 4096
+    pr = pairs[:m].long()
+    core = fit.core.bool()
+    instrip = core & (X[:, 0] >= float(lo)) & (X[:, 0] < float(hi))
+    assert bool(instrip[pr[:, 0]].all())                              # representatives are strip core points
+    assert torch.equal(fit.labels[pr[:, 0]].long(), pr[:, 1])         # ... with their own cluster id
+    assert len(torch.unique(pr[:, 0])) == m
+    P = X[instrip].double()
+    R = X[pr[:, 0]].double()
+    d2 = ((P[:, None, :] - R[None, :, :]) ** 2).sum(-1)
+    same = fit.labels[instrip].long()[:, None] == pr[None, :, 1]
+    near = ((d2 <= 64.0) & same).any(dim=1)
+    assert bool(near.all())
+    assert m < int(instrip.sum()) // 20                               # far fewer pairs than strip points
+    short, cnt2 = fit.strip_pairs(lo, hi, 3)
+    assert int(cnt2.item()) == m and short.shape == (3, 2)
+
+
 def test_dbscan_relabel_redecides_border_points(cuda, oracle_clib):
     """Swapping the ids of two clusters must move a border point that touches both to the other one."""
     a = np.column_stack([np.linspace(0, 1, 30), np.zeros(30), np.zeros(30)])
     b = np.column_stack([np.linspace(3.2, 4.2, 30), np.zeros(30), np.zeros(30)])
     X = np.vstack([b, [[2.1, 0, 0]], a]).astype(np.float32)            # the tie fixture: point 30 touches both
     dev = torch.from_numpy(X).to(cuda)
-    labels, core, k = ops.dbscan(dev, 1.15, 8, 0, want_core=True)
-    assert k == 2 and int(labels[30]) == 0 and not bool(core[30])
-    swapped = ops.dbscan_relabel(labels, torch.tensor([1, 0], dtype=torch.int32, device=cuda)).cpu().numpy()
+    fit = ops.DbscanFit(dev, 1.15, 8, 0)
+    assert fit.nclusters == 2 and int(fit.labels[30]) == 0 and not bool(fit.core[30])
+    # any number of other ops may run between the fit and its continuation: the fit owns its workspace
+    ops.percentile_f32(dev[:, 0].contiguous(), 25.0)
+    ops.segment_by_label(fit.labels.clone(), dev, 2)
+    assert fit.first_core_rows().tolist() == [0, 31]
+    swapped = fit.relabel(torch.tensor([1, 0], dtype=torch.int32, device=cuda)).cpu().numpy()
     assert (swapped[:30] == 1).all() and (swapped[31:] == 0).all()
     assert swapped[30] == 0                                            # smallest NEW id among its core neighbours
-    dropped = ops.dbscan_relabel(labels, torch.tensor([5, -1], dtype=torch.int32, device=cuda)).cpu().numpy()
+    dropped = fit.relabel(torch.tensor([5, -1], dtype=torch.int32, device=cuda)).cpu().numpy()
     assert (dropped[:30] == -1).all() and (dropped[31:] == 5).all() and dropped[30] == 5
+
+
+def test_dbscan_continuation_on_an_overwritten_workspace_is_refused(cuda):
+    """pch_dbscan_relabel_i32 / pch_dbscan_first_core_rows_i32 continue the grid the last pch_dbscan_f32 left in
+    its workspace.  A pch_* call that carves the same buffer in between must make them fail cleanly
+    (PCH_ERR_ARG) - never follow overwritten cell tables on the device."""
+    from pointcloudhookup_amd import _lib
+    L = _lib.lib()
+    X = synth.corridor_torch(20000, seed=synth.SEED0 + 31, kind="corridor", offset=False, device=cuda,
+                             dtype=torch.float32)
+    n = X.shape[0]
+    ws = torch.empty(int(L.pch_dbscan_ws_bytes(n)) + 256, dtype=torch.uint8, device=cuda)
+    labels = torch.empty(n, dtype=torch.int32, device=cuda)
+    ncl = torch.zeros(1, dtype=torch.int32, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def fit():
+        _lib.check(L.pch_dbscan_f32(X.data_ptr(), n, 8.0, 20, 0, None, labels.data_ptr(), 0, ncl.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), st))
+        return int(ncl.item())
+
+    k = fit()
+    assert k >= 1
+    rows = torch.empty(k, dtype=torch.int32, device=cuda)
+    assert L.pch_dbscan_first_core_rows_i32(n, rows.data_ptr(), ws.data_ptr(), ws.numel(), st) == 0
+    # another op on the SAME buffer (here: the percentile select) overwrites the grid
+    out = torch.empty(1, dtype=torch.float32, device=cuda)
+    z = X[:, 2].contiguous()
+    _lib.check(L.pch_percentile_f32(z.data_ptr(), n, 1, 0, 25.0, out.data_ptr(), ws.data_ptr(), ws.numel(), st))
+    cmap = torch.zeros(k, dtype=torch.int32, device=cuda)
+    before = labels.clone()
+    assert L.pch_dbscan_first_core_rows_i32(n, rows.data_ptr(), ws.data_ptr(), ws.numel(), st) == -1
+    assert b"untouched workspace" in L.pch_last_error()
+    assert L.pch_dbscan_relabel_i32(cmap.data_ptr(), k, n, labels.data_ptr(), ws.data_ptr(), ws.numel(), st) == -1
+    torch.cuda.synchronize()
+    assert torch.equal(labels, before)                                 # nothing was launched
+    # a sub-range of the buffer counts as well, a disjoint buffer does not
+    k = fit()
+    other = torch.empty(1 << 20, dtype=torch.uint8, device=cuda)
+    _lib.check(L.pch_percentile_f32(z.data_ptr(), n, 1, 0, 25.0, out.data_ptr(), other.data_ptr(), other.numel(), st))
+    assert L.pch_dbscan_first_core_rows_i32(n, rows.data_ptr(), ws.data_ptr(), ws.numel(), st) == 0
+    _lib.check(L.pch_percentile_f32(z.data_ptr(), n, 1, 0, 25.0, out.data_ptr(), ws.data_ptr() + 4096,
+                                    ws.numel() - 4096, st))
+    assert L.pch_dbscan_first_core_rows_i32(n, rows.data_ptr(), ws.data_ptr(), ws.numel(), st) == -1
+
+
+def test_lookback_wait_is_bounded(cuda):
+    """The single-pass compactions chain their workgroups by a look-back poll (pch_lookback.h).  That wait has a
+    wall-clock budget: with a tile that never publishes (the self-test kernel withholds ticket 1) the tiles behind it
+    must give up, poison their status words and let the grid drain - the call comes back with PCH_ERR_TIMEOUT
+    instead of leaving a spinning grid on the GPU.  The data-path kernels use the same function with a 4 s budget
+    and report through a negative count (ops raise PchError)."""
+    import time
+    from pointcloudhookup_amd import _lib
+    L = _lib.lib()
+    scratch = torch.empty(256, dtype=torch.uint8, device=cuda)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rc = L.pch_selftest_lookback_timeout(50, scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream)
+    dt = time.perf_counter() - t0
+    assert rc == _lib.PCH_ERR_TIMEOUT, L.pch_last_error()
+    assert 0.04 < dt < 1.5, dt                                        # two waiters, 50 ms each at most, not 4 s
+    with pytest.raises(_lib.PchError, match="PCH_ERR_TIMEOUT"):
+        _lib.check_count(-(1 << 62) + 5, "x")
+    assert _lib.check_count(7, "x") == 7
+    # and the data path is unaffected: an ordinary filter still gives its count
+    raw = synth.corridor_torch(300_000, seed=synth.SEED0 + 12, kind="corridor", offset=True, device=cuda,
+                               dtype=torch.float32)
+    assert ops.ground_filter(raw)["count"] > 0
 
 
 def test_build_then_smoke_in_one_process(cuda):

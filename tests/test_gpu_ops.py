@@ -168,6 +168,46 @@ def test_mean_seq_distributions(cuda, name):
         np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+def _chained(raw, cuts, cuda):
+    """np.mean over shards chained in file order: running sums handed from shard to shard, the last one divides"""
+    run = None
+    bounds = [0] + list(cuts) + [len(raw)]
+    for k in range(len(bounds) - 1):
+        part = _dev(raw[bounds[k]:bounds[k + 1]], cuda)
+        last = k == len(bounds) - 2
+        run = ops.mean_seq_partial_f32(part, run, total_n=len(raw) if last else 0)
+    return run.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", [c[0] for c in _mean_cases()])
+def test_mean_seq_sharded_equals_numpy(cuda, name):
+    """Three file-order shards chained through pch_mean_seq_partial_f32 (12 bytes per hop) give
+    np.mean(concatenation, axis=0) bit for bit on the adversarial distributions of the unsharded test - the shard
+    cuts fall inside 1024-row blocks, on a block edge and next to the array's ends."""
+    raw = dict(_mean_cases())[name]
+    n = len(raw)
+    with np.errstate(all="ignore"):
+        ref = np.mean(raw, axis=0)
+    for cuts in ((n // 3 + 5, 2 * n // 3 + 1), (1024 * 200, 1024 * 200 + 1), (1, n - 1), (0, n), (n // 2, n // 2)):
+        got = _chained(raw, cuts, cuda)
+        if np.isnan(ref).any():
+            assert (np.isnan(got) == np.isnan(ref)).all(), (name, cuts)
+            np.testing.assert_array_equal(got[~np.isnan(ref)], ref[~np.isnan(ref)])
+        else:
+            np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32), err_msg=f"{name} {cuts}")
+
+
+def test_mean_seq_sharded_corridor_8_shards(cuda):
+    """Config 4's shape: 8 consecutive shards of an EPSG-scale corridor (12 M rows), sums passed down the line."""
+    raw = synth.corridor_numpy(12_000_000, seed=synth.SEED0 + 9, kind="corridor", offset=True).astype(np.float32)
+    n = len(raw)
+    cuts = [n * k // 8 + (k % 3) for k in range(1, 8)]
+    got = _chained(raw, cuts, cuda)
+    np.testing.assert_array_equal(got.view(np.uint32), np.mean(raw, axis=0).view(np.uint32))
+    one = ops.mean_seq_f32(_dev(raw, cuda)).cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.uint32), one.view(np.uint32))
+
+
 def test_mean_seq_stagnation_40m(cuda):
     """float32 running sums that stop growing (ulp/2 > element): 40 M rows at EPSG:4547 scale."""
     n = 40_000_000
