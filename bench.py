@@ -198,11 +198,17 @@ def run_tiled(points_total, kind, frame, rank, world, dev, steps, warmup, seed, 
     for _ in range(max(warmup, 1)):
         res = step()
     barrier()
+    trace = {"trace": []} if os.environ.get("PCH_BENCH_TRACE") else None
     t0 = time.perf_counter()
     for _ in range(steps):
-        res = step()
+        res = step(trace)
     barrier()
     elapsed = time.perf_counter() - t0
+    if trace:                                              # host timestamps of every phase of every timed step, per rank
+        prev = t0
+        for label, ts in trace["trace"]:
+            print(f"[trace rank {rank}] {label:18s} +{1e3 * (ts - prev):10.3f} ms", file=sys.stderr)
+            prev = ts
     tm = {}
     for _ in range(2):                                     # phase split on two extra steps (adds syncs: not timed above)
         step(tm)
@@ -300,10 +306,12 @@ def main():
     if env_world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: start it either plainly "
                          f"(it launches its own ranks) or under torch.distributed.run with --nproc-per-node {args.gpus}")
-    if os.environ.get("PCH_BENCH_SINGLE_DEVICE") and env_world > 4:
-        # a rehearsal mode (ranks sharing one device over gloo); five processes on one GPU have stalled before
-        #  - refused before any GPU work
-        raise SystemExit("bench.py: PCH_BENCH_SINGLE_DEVICE supports at most 4 ranks on the one device")
+    if os.environ.get("PCH_BENCH_SINGLE_DEVICE") and env_world > 3 and not os.environ.get("PCH_BENCH_ALLOW_STALLS"):
+        # a rehearsal mode (ranks sharing one device over gloo).  From four processes on, this platform stalls ALL
+        # device work of all of them for seconds at a time (profiles/r03_shared_device_stalls.txt, DESIGN.md
+        # section 9): results stay correct, timings are meaningless - refused before any GPU work
+        raise SystemExit("bench.py: PCH_BENCH_SINGLE_DEVICE supports at most 3 ranks on the one device "
+                         "(PCH_BENCH_ALLOW_STALLS=1 overrides)")
 
     if os.environ.get("PCH_BENCH_DRYRUN"):
         return dryrun(args)
@@ -319,7 +327,7 @@ def main():
         local = 0
     elif torch.cuda.device_count() < world:
         raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s) visible "
-                         "(PCH_BENCH_SINGLE_DEVICE=1 rehearses up to 4 ranks on one device over gloo)")
+                         "(PCH_BENCH_SINGLE_DEVICE=1 rehearses up to 3 ranks on one device over gloo)")
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     if args.mode == "tiled":                                 # BASELINE configs[3]: the whole line is the tiled run

@@ -182,6 +182,14 @@ class HipFit:
         return self._fit.relabel(cmap)
 
 
+def _mark(timings, label):
+    """timings["trace"] (a list, if present) receives (label, perf_counter()) - host timestamps only, no
+    synchronisation is added (tools: where does a tiled step spend its wall clock?)"""
+    if timings is not None and "trace" in timings:
+        import time
+        timings["trace"].append((label, time.perf_counter()))
+
+
 # capacities of the two fixed-size exchanges of cluster_tiled (per rank): clusters, strip pairs, links.  A rank that
 # holds more is seen by everybody in the block's header and ONE exactly sized exchange follows (same branch on all)
 TILED_KCAP, TILED_PCAP, TILED_LCAP = 2048, 4096, 1024
@@ -266,6 +274,7 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
     labels, core, k = fit.fit(points)
     k = int(k)
     t_fit = time.perf_counter()                            # fit() has read the cluster count: the device is drained
+    _mark(timings, "fit")
     single = not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1
     # bookkeeping stays where the points are (device tensors with the HIP fit): only the per-cluster table and
     # the pairs of the strip cells ever leave the device
@@ -286,7 +295,8 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
         minrow = minrow[:k]
 
     def done(labels_out, total):
-        if timings is not None:
+        _mark(timings, "relabel_enqueued")
+        if timings is not None and "trace" not in timings:
             if torch.as_tensor(labels_out).is_cuda:
                 torch.cuda.synchronize(wdev)
             t_end = time.perf_counter()
@@ -330,7 +340,9 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
             strip = cm & (x_d >= e_hi - float(eps)) & (x_d < e_hi + float(eps))
             pairs = torch.stack([rows_d[strip], lab_d[strip]], dim=1).reshape(-1)   # (global row, LOCAL cluster id)
             npairs2 = int(pairs.numel())
+        _mark(timings, "pairs_built")
         got, need = _exchange([k, npairs2], [minrow, pairs], [TILED_KCAP, 2 * pcap], comm_dev, group)
+        _mark(timings, "exchange1")
         if not hasattr(fit, "strip_pairs") or need[1] <= 2 * pcap:
             break
         pcap = need[1] // 2                                # some strip has more cells than the pair buffer: once more
@@ -345,7 +357,9 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
         if hit.any():
             links = torch.unique(torch.stack([theirs[hit, 1] + int(offs[rank - 1]), lab_d[at[hit]] + int(offs[rank])],
                                              dim=1), dim=0)
+    _mark(timings, "links_built")
     got2, _ = _exchange([2 * int(links.shape[0])], [links.reshape(-1)], [2 * TILED_LCAP], comm_dev, group)
+    _mark(timings, "exchange2")
     if total == 0:
         return done(fit.relabel(torch.zeros(0, dtype=torch.int32)), 0)
     # union over all local clusters (uid = rank offset + local id): components of the link graph, numbered by the
@@ -474,7 +488,7 @@ class HipMeanShard:
         return self._sh.walk(sum_in, total_n)
 
 
-def sharded_centroid(own_rows, total_n, shard=None, group=None):
+def sharded_centroid(own_rows, total_n, shard=None, group=None, timings=None):
     """np.mean(concatenation of every rank's rows in RANK order, axis=0) of float32 [n_r,3] shards, bit for bit:
     numpy's sum is sequential per column, so the three running float32 sums travel down the line of ranks
     (12 bytes per hop, one send/recv each) and the last rank divides by float32(total_n) and broadcasts.  Every rank
@@ -484,6 +498,7 @@ def sharded_centroid(own_rows, total_n, shard=None, group=None):
     if int(total_n) == 0:                                  # np.mean of an empty array: 0 / 0 (every rank knows total_n)
         return np.full(3, np.nan, dtype=np.float32)
     shard = shard or HipMeanShard(own_rows)
+    _mark(timings, "c.tables_enqueued")
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     if not multi:
         return torch.as_tensor(shard.walk(None, int(total_n))).cpu().numpy().astype(np.float32)
@@ -494,14 +509,17 @@ def sharded_centroid(own_rows, total_n, shard=None, group=None):
     if rank > 0:
         buf = torch.empty(3, dtype=torch.float32, device=comm_dev)
         dist.recv(buf, src=dist.get_global_rank(group, rank - 1) if group is not None else rank - 1, group=group)
+        _mark(timings, "c.recv")
         sum_in = buf.to(wdev)
     last = rank == world - 1
     out = torch.as_tensor(shard.walk(sum_in, int(total_n) if last else 0)).to(comm_dev, torch.float32)
+    _mark(timings, "c.walk_done")
     if not last:
         dist.send(out, dst=dist.get_global_rank(group, rank + 1) if group is not None else rank + 1, group=group)
         out = torch.empty(3, dtype=torch.float32, device=comm_dev)
     src = dist.get_global_rank(group, world - 1) if group is not None else world - 1
     dist.broadcast(out, src=src, group=group)
+    _mark(timings, "c.bcast")
     return out.cpu().numpy().astype(np.float32)
 
 
@@ -543,8 +561,11 @@ def tiled_step(tile, tile_rows, own, total_n, x_lo, x_hi, eps=8.0, min_samples=8
     t0 = time.perf_counter()
     own_idx = torch.nonzero(own).flatten()
     own_rows = tile[own_idx] if own_idx.numel() != tile.shape[0] else tile
-    centroid = sharded_centroid(own_rows.contiguous(), total_n, group=group)
+    _mark(timings, "start")
+    centroid = sharded_centroid(own_rows.contiguous(), total_n, group=group, timings=timings)
+    _mark(timings, "centroid")
     base = shared_percentile(own_rows[:, 2], pct, sub=centroid[2], group=group)
+    _mark(timings, "percentile")
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
     def filtered(off):
@@ -565,10 +586,11 @@ def tiled_step(tile, tile_rows, own, total_n, x_lo, x_hi, eps=8.0, min_samples=8
         thr, kept, loc, own_k, survivors = filtered(fallback_offset)
         used_fallback = True
     t1 = time.perf_counter()
+    _mark(timings, "filter")
     cx = float(centroid[0])                                # the kept points are centred: so are the edges
     labels, K = cluster_tiled(kept["points"], tile_rows[loc], own_k, float(x_lo) - cx, float(x_hi) - cx, eps,
                               min_samples, halo=halo, group=group, timings=timings)
-    if timings is not None:
+    if timings is not None and "trace" not in timings:
         timings["filter_ms"] = timings.get("filter_ms", 0.0) + 1e3 * (t1 - t0)
     return dict(centroid=centroid, threshold=thr, used_fallback=used_fallback, points=kept["points"],
                 rows=tile_rows[loc], own=own_k, labels=labels, nclusters=int(K), survivors=survivors)

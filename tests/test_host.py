@@ -297,9 +297,9 @@ def test_bench_launches_its_own_ranks():
     # --gpus that contradicts the launcher's world size is an error, not a silent single-rank run
     r = _bench("--gpus", "4", PCH_BENCH_DRYRUN="1", RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
-    # more than 4 ranks on one shared device are refused before any GPU work
-    r = _bench("--gpus", "5", PCH_BENCH_SINGLE_DEVICE="1", RANK="0", WORLD_SIZE="5", LOCAL_RANK="0")
-    assert r.returncode != 0 and "at most 4 ranks" in r.stderr
+    # more than 3 ranks on one shared device are refused before any GPU work
+    r = _bench("--gpus", "4", PCH_BENCH_SINGLE_DEVICE="1", RANK="0", WORLD_SIZE="4", LOCAL_RANK="0")
+    assert r.returncode != 0 and "at most 3 ranks" in r.stderr
 
 
 def test_dedup_centres_first_wins():
