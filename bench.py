@@ -182,7 +182,7 @@ def run_tiled(points_total, kind, frame, rank, world, dev, steps, warmup, seed, 
     import numpy as np
     t = synth.corridor_tile_torch(points_total, rank, world, HALO, seed=seed, kind=kind, offset=(frame == "offset"),
                                   device=dev, dtype=torch.float32)
-    tile, own = t["points"], t["own"]
+    tile, own = t["points"], t["own_range"]
     rows, total = tiles.global_rows(t["local_row"], t["n_own"])
     assert total == points_total, (total, points_total)
     torch.cuda.synchronize()
@@ -443,11 +443,47 @@ def main():
                                             peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None)
     knn = next((roof(r[0], r[1]) for r in kernels if r[0] == "db_core"), None)
     if knn:
-        knn["model"] = ("SURVEY 8d tile formula on the kernel's cell grid (side eps/sqrt(3)), summed over the query "
-                        "cells on the distance-test path (fewer than min_samples points); denser cells are core "
-                        "without a test and are priced at their output only")
-        knn["bytes_per_launch_all_cells"] = int(knn_bytes_all)
-        knn["frac_all_cells"] = round(knn_bytes_all / (knn["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        # The radius kernel is not bound by HBM: its figure of merit is
+        # pair tests per second.  The byte MODELS of SURVEY 8(d) stay in the line, after the counter-based figures,
+        # labelled as models: they price L2/LDS-resident tile reuse as HBM bytes, which the counters show never moved.
+        knn = {"kernel": "db_core", "avg_ms": knn["avg_ms"],
+               "bound": "not HBM: vector-ALU issue on sparse data, load latency where few cells reach the test path "
+                        "(see valu_issue_frac_measured / wave_wait_frac_measured)",
+               "hbm_model": {"note": "SURVEY 8d tile formula, NOT measured traffic: 12*sum of the points of the "
+                                     "occupied neighbour cells + 4*N_f; 'sparse_cells' = on the kernel's own grid "
+                                     "(side eps/sqrt(3)) over the query cells below min_samples only, 'all_cells' = "
+                                     "as written (side eps, every cell)",
+                             "bytes_sparse_cells": int(knn_bytes), "frac_sparse_cells": knn["frac"],
+                             "bytes_all_cells": int(knn_bytes_all),
+                             "frac_all_cells": round(knn_bytes_all / (knn["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+        if world == 1 and not args.no_side:
+            try:                                         # the same fit once more in the counting variant of the kernel
+                ops.set_pair_counting(True)
+                fitc = ops.DbscanFit(cl["ground"]["points"], EPS, MIN_POINTS, CHUNK, aabb=cl["ground"]["aabb"])
+                st = fitc.pair_stats()
+                same = bool(torch.equal(fitc.labels, cl["labels"]))
+                del fitc
+                t_s = knn["avg_ms"] * 1e-3
+                lane_rate = 1024 * 16 * 2.4e9              # SIMDs x lanes per clock x max clock (MI355X_MICROARCH.md)
+                knn.update({
+                    "pair_tests": st["pair_tests"], "lane_slots_issued": st["lane_slots"],
+                    "lane_utilisation": round(st["pair_tests"] / max(st["lane_slots"], 1), 4),
+                    "cells_on_the_test_path": st["cells_tested"], "lds_tiles_staged": st["tiles_staged"],
+                    "pair_tests_per_s": round(st["pair_tests"] / t_s, 1),
+                    "lane_slots_per_s": round(st["lane_slots"] / t_s, 1),
+                    "valu_peak_lane_instr_per_s": lane_rate,
+                    "valu_instr_per_test_model": 7,
+                    "frac_valu_model": round(st["lane_slots"] * 7 / lane_rate / t_s, 4),
+                    "counting_variant_labels_identical": same,
+                    "pair_tests_note": "counted by the kernel's counting variant (same control flow, "
+                                       "pch_dbscan_set_pair_counting) on the timed tile; rates use the plain kernel's "
+                                       "hipEvent time; frac_valu_model = issued lane slots x 7 vector instructions per "
+                                       "test / (1024 SIMDs x 16 lanes x 2.4 GHz); the measured issue occupancy is "
+                                       "`valu_issue_frac_measured` (SQ_INSTS_VALU, profiles/)"})
+            except Exception as e:
+                knn["pair_tests_error"] = f"{type(e).__name__}: {e}"
+            finally:
+                ops.set_pair_counting(False)
     if roofline.get("kernel") == "mean_walk":
         roofline["note"] = ("largest kernel by time is the exact-centroid walk: a serial dependency chain on "
                             "3 wavefronts (latency-bound); see streaming_kernel for the largest HBM-bound kernel")
@@ -455,6 +491,7 @@ def main():
                    if r[0] not in ("mean_walk", "db_core", "db_union0", "db_union1", "db_border")
                    and algorithmic_bytes(r[0], N, NF)), None)
     tr_path = os.path.join(ROOT, "profiles", "traffic.json")   # PMC passes, see profiles/README.md
+    step_traffic = None
     if os.path.exists(tr_path):
         try:
             tr = json.load(open(tr_path)).get("workloads", {}).get(f"{args.kind}/{args.frame}/{N}")
@@ -463,8 +500,29 @@ def main():
                     r["traffic"] = tr["kernels"][r["kernel"]]
                     r["traffic_source"] = f"profiles/{tr.get('source')}_pmc_traffic.csv"
                     r["frac_traffic"] = round(r["traffic"] / (r["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                if r and tr and r["kernel"] in tr.get("sq", {}):
+                    sqk = tr["sq"][r["kernel"]]
+                    r["valu_issue_frac_measured"] = sqk.get("valu_issue_frac")
+                    if sqk.get("SQ_WAVE_CYCLES"):
+                        r["wave_wait_frac_measured"] = round(sqk.get("SQ_WAIT_ANY", 0) / sqk["SQ_WAVE_CYCLES"], 4)
+                    r["sq_source"] = f"profiles/{tr.get('source')}_sq_counters.csv"
+            if tr and tr.get("step_bytes"):
+                # every kernel of one step, from the counter passes, against what one step must move at least:
+                # the tile once (12 B/pt) + the z column written and read (8) + per kept point the row out (12), the
+                # sorted copy written and read (32), labels (4) and the grouped index (4)
+                compulsory = 20 * N + 52 * NF
+                step_traffic = {"bytes_per_step": tr["step_bytes"], "compulsory_bytes_per_step": compulsory,
+                                "amplification": round(tr["step_bytes"] / compulsory, 3),
+                                "achieved_GBps": round(tr["step_bytes"] / (ms_per_step * 1e-3) / 1e9, 1),
+                                "frac_of_hbm_peak": round(tr["step_bytes"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "launches_per_step_profiled": tr.get("launches_per_step"),
+                                "source": f"profiles/{tr.get('source')}_pmc_traffic.csv (all pch kernels, "
+                                          "2*FETCH_SIZE + WRITE_SIZE)"}
         except Exception:
             pass
+    if knn and knn.get("traffic") is not None:
+        knn["hbm_counters"] = {"bytes": knn.pop("traffic"), "frac_of_hbm_peak": knn.pop("frac_traffic"),
+                               "source": knn.pop("traffic_source")}
 
     out = {
         "metric": "Mpts/s ground-filter+tower-cluster, 100 M-pt corridor; % HBM roofline on kNN",
@@ -486,6 +544,7 @@ def main():
         "kernels": [dict(name=r[0], avg_ms=round(r[1], 4), launches_per_step=r[2] / args.steps,
                          ms_per_step=round(r[3], 4)) for r in kernels[:12]],
         "knn_cell_occupancy": occ,
+        "step_traffic": step_traffic,
         "tiled": tiled_res,
     }
 

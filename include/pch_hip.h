@@ -144,9 +144,11 @@ int pch_mean_seq_f32(const float* xyz, int64_t n, float* out_centroid,
  * builds them at once, sum_in3 / out3 are ignored); 2 = only the short serial walk over the tables a phase-1 call
  * left in the SAME workspace (the caller keeps that workspace untouched in between) - so that along a chain of
  * shards only the walks (~0.1-0.3 ms each) are serial, not the passes over the rows.
+ * zcol_out (optional, [n] float32): receives a contiguous copy of the z column, written by the table pass that
+ * reads the rows anyway (phases 0 and 1) - what the percentile passes of stage B2 then read instead of the rows.
  * Workspace: pch_mean_seq_f32_ws_bytes(n).  Replaces: utils/tower_extraction.py:63 on a sharded array. */
 int pch_mean_seq_partial_f32(const float* xyz, int64_t n, const float* sum_in3, int64_t total_n,
-                             float* out3, int32_t phase, void* ws, size_t ws_bytes, void* stream);
+                             float* out3, float* zcol_out, int32_t phase, void* ws, size_t ws_bytes, void* stream);
 /* same result from one workgroup adding element by element (O(n) serial; kept only to
  * cross-check the parallel algorithm above) */
 int pch_mean_seq_serial_f32(const float* xyz, int64_t n, float* out_centroid, void* stream);
@@ -246,6 +248,16 @@ int pch_dbscan_relabel_i32(const int32_t* map, int32_t nmap, int64_t n, int32_t*
 /* Smallest core row of every cluster of that same last call (the row that gives a cluster its number in
  * sklearn's sweep): out_rows [nclusters] int32, ascending.  Same workspace rule as the relabel call. */
 int pch_dbscan_first_core_rows_i32(int64_t n, int32_t* out_rows, void* ws, size_t ws_bytes, void* stream);
+
+/* Measurement of the radius kernel in the currency that bounds it ("pair-tests/s").  With counting
+ * enabled (per thread) pch_dbscan_f32 runs the radius-count kernel in a variant with the SAME control flow that
+ * tallies its distance tests; pch_dbscan_pair_stats then reads, from the fit's untouched workspace,
+ *   out4_host[0] useful pair tests (a real query point against a real candidate point),
+ *   out4_host[1] issued lane slots (64 per wave instruction group: padding and idle lanes included),
+ *   out4_host[2] cells that reached the distance-test path, out4_host[3] LDS candidate tiles staged.
+ * The counting variant is slower: time the plain kernel, count with this one (bench.py does).  Synchronises. */
+void pch_dbscan_set_pair_counting(int enable);
+int pch_dbscan_pair_stats(int64_t n, uint64_t* out4_host, void* ws, size_t ws_bytes, void* stream);
 
 /* The (row, cluster) pairs a tile publishes to its neighbour for the cross-tile reconciliation (config 4,
  * pointcloudhookup_amd/tiles.py): of that same last fit, ONE pair per grid cell that holds a core point with

@@ -41,7 +41,7 @@ _SIGS = {
     "pch_cast_f64_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pch_mean_seq_f32_ws_bytes": (_sz, [_i64]),
     "pch_mean_seq_f32": (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
-    "pch_mean_seq_partial_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _sz, _vp]),
+    "pch_mean_seq_partial_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _sz, _vp]),
     "pch_mean_seq_serial_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pch_percentile_f32_ws_bytes": (_sz, [_i64]),
     "pch_percentile_f32": (C.c_int, [_vp, _i64, _i64, _vp, _f64, _vp, _vp, _sz, _vp]),
@@ -56,6 +56,8 @@ _SIGS = {
     "pch_first_nonfinite_row_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pch_dbscan_relabel_i32": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _sz, _vp]),
     "pch_dbscan_first_core_rows_i32": (C.c_int, [_i64, _vp, _vp, _sz, _vp]),
+    "pch_dbscan_set_pair_counting": (None, [C.c_int]),
+    "pch_dbscan_pair_stats": (C.c_int, [_i64, _vp, _vp, _sz, _vp]),
     "pch_dbscan_strip_pairs_i32": (C.c_int, [_i64, _f32, _f32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "pch_dbscan_ws_bytes": (_sz, [_i64]),
     "pch_dbscan_f32": (C.c_int, [_vp, _i64, _f64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -684,12 +684,25 @@ __global__ __launch_bounds__(DB_THREADS) void db_rowtab_k(DbGrid g, const uint64
 // query point of the cell, candidate tiles (64 points of the sorted neighbour runs) are staged
 // once in LDS and broadcast to all queries; the wave leaves as soon as every query has reached
 // min_samples (checked per tile).  Each candidate is loaded once per cell, not once per query.
+// COUNT (measurement builds of the SAME control flow, pch_dbscan_set_pair_counting): the wave tallies the distance
+// tests it makes - useful ones (a real query against a real candidate) and issued lane slots (64 per
+// wave-instruction group, padding and idle lanes included) - and adds them to stats[0..3] once, at its end:
+// [0] useful pair tests, [1] issued lane slots, [2] cells that reached the test path, [3] LDS tiles staged.
+template <bool COUNT>
 __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* __restrict__ pts,
                                                         const uint32_t* __restrict__ cell_start,
                                                         const uint64_t* __restrict__ cell_key, int m,
                                                         const int2* __restrict__ rowtab,
                                                         uint8_t* __restrict__ core_s,
-                                                        uint32_t* __restrict__ cell_ncore) {
+                                                        uint32_t* __restrict__ cell_ncore,
+                                                        unsigned long long* __restrict__ stats) {
+    unsigned long long n_useful = 0, n_slots = 0, n_tiles = 0;
+    auto tally = [&]() {
+        if (COUNT && lane_id() == 0) {
+            atomicAdd(&stats[0], n_useful); atomicAdd(&stats[1], n_slots);
+            atomicAdd(&stats[2], 1ull); atomicAdd(&stats[3], n_tiles);
+        }
+    };
     __shared__ RowSet rows[DB_WAVES];
     __shared__ DbPair tiles[DB_WAVES][32];
     __shared__ uint32_t seg_a[DB_WAVES][DB_SEGS], seg_b[DB_WAVES][DB_SEGS];
@@ -760,6 +773,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
                     bool hit = false;
                     if (j < pb) hit = db_within2(qp, pts[j], g);
                     count += (int)__popcll(__ballot(hit));
+                    if (COUNT) { n_useful += (pb - j0) < 64u ? (pb - j0) : 64u; n_slots += 64; }
                 }
             }
             const bool is_core = count >= g.min_samples;
@@ -767,6 +781,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
             ncore += is_core;
         }
         if (l == 0) cell_ncore[c] = ncore;
+        tally();
         return;
     }
     DbPair* tile = tiles[wave_id()];
@@ -792,6 +807,11 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
             db_tile_put(tile, l, P);
             __builtin_amdgcn_wave_barrier();
             count += db_tile_count(Q, tile, nj, g);
+            if (COUNT) {
+                n_useful += (unsigned long long)__popcll(__ballot(valid)) * (unsigned)nj;
+                n_slots += 64ull * (unsigned)((nj + 7) & ~7);
+                ++n_tiles;
+            }
             j0 += 64;
             active = __ballot(valid && count < g.min_samples);
         }
@@ -811,6 +831,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
                 bool hit = false;
                 if (j < pb) hit = db_within2(qp, pts[j], g);
                 cq += (int)__popcll(__ballot(hit));
+                if (COUNT) { n_useful += (pb - jj) < 64u ? (pb - jj) : 64u; n_slots += 64; }
                 jj += 64;
             }
             if (l == ql) count = cq;
@@ -820,6 +841,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
         ncore += (uint32_t)__popcll(__ballot(is_core));
     }
     if (l == 0) cell_ncore[c] = ncore;
+    tally();
 }
 
 // ---- per-cell box of the core points, union-find init ----------------------------------
@@ -1537,11 +1559,13 @@ struct DbWs {
     uint32_t* chunk_cells;
     uint32_t* comp;          // [n][3] compressed cell coordinates (fallback for grids beyond the 64-bit key)
     uint32_t* flag2;         // [n + 8] head flags kept beside their scan
+    unsigned long long* core_stats;   // [4] tallies of db_core_k<true> (pch_dbscan_set_pair_counting)
 };
 
 static void db_plan(Arena& a, int64_t n, DbWs& w) {
     const int64_t nn = n > 0 ? n : 1;
     w.meta = a.take<uint32_t>(16);
+    w.core_stats = a.take<unsigned long long>(4);
     w.chunk_bad = a.take<uint32_t>(nn + 8);              // one word per chunk (chunk_size >= 1)
     w.chunk_cells = a.take<uint32_t>(nn + 8);
     w.k0 = a.take<uint64_t>(nn);
@@ -1586,6 +1610,8 @@ static int db_sort_mode() {
     }
     return m;
 }
+
+static thread_local bool g_count_pairs = false;
 
 // what pch_dbscan_relabel_i32 needs to know about the run whose workspace it continues
 struct DbLastRun { void* ws; size_t ws_bytes; int64_t n; int m; DbGrid g; bool has_rowtab; };
@@ -1842,8 +1868,16 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
                    g, (const uint64_t*)w.cell_key, m, w.rowtab);
         rowtab = w.rowtab;
     }
-    PCH_LAUNCH("db_core", db_core_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
-               (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, w.core_s, w.cell_ncore);
+    if (g_count_pairs) {
+        PCH_HIP_TRY(hipMemsetAsync(w.core_stats, 0, 4 * sizeof(unsigned long long), s));
+        PCH_LAUNCH("db_core_counting", db_core_k<true>, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
+                   (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, w.core_s, w.cell_ncore,
+                   w.core_stats);
+    } else {
+        PCH_LAUNCH("db_core", db_core_k<false>, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
+                   (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, w.core_s, w.cell_ncore,
+                   (unsigned long long*)nullptr);
+    }
     PCH_HIP_TRY(hipMemsetAsync(w.cell_acc, 0, sizeof(uint32_t) * 8 * (size_t)m, s));
     PCH_LAUNCH("db_cellstats", db_cellstats_k, dim3((unsigned)ceil_div(n, (int64_t)DB_WAVES * 64 * DB_CS_ROUNDS)),
                dim3(DB_THREADS), 0, s, (const float4*)w.pts, (const uint32_t*)w.cid, (const uint8_t*)w.core_s, n,
@@ -1913,6 +1947,25 @@ extern "C" int pch_dbscan_first_core_rows_i32(int64_t n, int32_t* out_rows, void
     const uint32_t* wrank = w.flag + ((nw + 63) & ~int64_t(63));
     PCH_LAUNCH("db_first_rows", db_first_rows_k, dim3((unsigned)ceil_div(nw, DB_THREADS)), dim3(DB_THREADS), 0,
                (hipStream_t)stream, bits, wrank, nw, out_rows);
+    return PCH_OK;
+}
+
+extern "C" void pch_dbscan_set_pair_counting(int enable) { g_count_pairs = enable != 0; }
+
+extern "C" int pch_dbscan_pair_stats(int64_t n, uint64_t* out4_host, void* ws, size_t ws_bytes, void* stream) {
+    PCH_DEVICE_GUARD(ws);
+    PCH_REQUIRE(n >= 0 && out4_host, "bad argument");
+    memset(out4_host, 0, 4 * sizeof(uint64_t));
+    if (n == 0) return PCH_OK;
+    if (g_last.ws != ws || g_last.ws_bytes != ws_bytes || g_last.n != n || ws == nullptr) {
+        set_error("pch_dbscan_pair_stats must follow pch_dbscan_f32 of this thread on the same, untouched workspace");
+        return PCH_ERR_ARG;
+    }
+    Arena a(ws, ws_bytes, true);
+    DbWs w;
+    db_plan(a, n, w);
+    PCH_HIP_TRY(hipMemcpyAsync(out4_host, w.core_stats, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    PCH_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return PCH_OK;
 }
 

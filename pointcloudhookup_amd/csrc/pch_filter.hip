@@ -842,7 +842,8 @@ extern "C" int pch_mean_seq_f32(const float* xyz, int64_t n, float* out_centroid
 }
 
 extern "C" int pch_mean_seq_partial_f32(const float* xyz, int64_t n, const float* sum_in3, int64_t total_n,
-                                        float* out3, int32_t phase, void* ws, size_t ws_bytes, void* stream) {
+                                        float* out3, float* zcol_out, int32_t phase, void* ws, size_t ws_bytes,
+                                        void* stream) {
     PCH_DEVICE_GUARD(ws);
     PCH_REQUIRE(n >= 0 && total_n >= 0 && ws && phase >= 0 && phase <= 2, "bad argument");
     PCH_REQUIRE(phase == MS_PHASE_TABLES || out3, "null output");
@@ -851,7 +852,7 @@ extern "C" int pch_mean_seq_partial_f32(const float* xyz, int64_t n, const float
     MsWs w;
     ms_plan(a, n, w);
     if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
-    return mean_seq_launch(xyz, n, out3, w, nullptr, (hipStream_t)stream, nullptr, sum_in3,
+    return mean_seq_launch(xyz, n, out3, w, zcol_out, (hipStream_t)stream, nullptr, sum_in3,
                            total_n > 0 ? total_n : MS_NO_DIVIDE, phase);
 }
 

@@ -176,15 +176,17 @@ class MeanShard:
     shard, so every rank does this at once), ``walk`` then continues GIVEN running sums over them (the short serial
     part that is chained from rank to rank).  The tables live in a workspace that belongs to this object."""
 
-    def __init__(self, xyz):
+    def __init__(self, xyz, want_zcol=False):
         L = _lib.lib()
         self.xyz = _need_cuda(xyz, torch.float32, "xyz").reshape(-1, 3)
         self.n, self.device = self.xyz.shape[0], self.xyz.device
         with torch.cuda.device(self.device):
             self.workspace = torch.empty(int(L.pch_mean_seq_f32_ws_bytes(self.n)) + 256, dtype=torch.uint8,
                                          device=self.device)
-            _lib.check(L.pch_mean_seq_partial_f32(_ptr(self.xyz), self.n, 0, 0, 0, 1, _ptr(self.workspace),
-                                                  self.workspace.numel(), _stream()))
+            # contiguous copy of the z column, written by the pass that reads the rows anyway
+            self.zcol = torch.empty((self.n,), dtype=torch.float32, device=self.device) if want_zcol else None
+            _lib.check(L.pch_mean_seq_partial_f32(_ptr(self.xyz), self.n, 0, 0, 0, _ptr(self.zcol), 1,
+                                                  _ptr(self.workspace), self.workspace.numel(), _stream()))
 
     def walk(self, sum_in=None, total_n=0):
         L = _lib.lib()
@@ -192,7 +194,7 @@ class MeanShard:
             sum_in = _need_cuda(sum_in, torch.float32, "sum_in").reshape(3)
         out = torch.empty((3,), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(L.pch_mean_seq_partial_f32(_ptr(self.xyz), self.n, _ptr(sum_in), int(total_n), _ptr(out), 2,
+            _lib.check(L.pch_mean_seq_partial_f32(_ptr(self.xyz), self.n, _ptr(sum_in), int(total_n), _ptr(out), 0, 2,
                                                   _ptr(self.workspace), self.workspace.numel(), _stream()))
         return out
 
@@ -357,6 +359,17 @@ class DbscanFit:
                                                         self.workspace.numel(), _stream()))
         return out
 
+    def pair_stats(self):
+        """Tallies of the radius-count kernel of THIS fit, if it ran with ops.set_pair_counting(True): dict(pair_tests,
+        lane_slots, cells_tested, tiles_staged) (pch_dbscan_pair_stats).  Synchronises."""
+        import ctypes as C
+        L = _lib.lib()
+        out = (C.c_uint64 * 4)()
+        with torch.cuda.device(self.device):
+            _lib.check(L.pch_dbscan_pair_stats(self.n, C.cast(out, C.c_void_p), _ptr(self.workspace),
+                                               self.workspace.numel(), _stream()))
+        return dict(pair_tests=int(out[0]), lane_slots=int(out[1]), cells_tested=int(out[2]), tiles_staged=int(out[3]))
+
     def strip_pairs(self, x_lo, x_hi, cap=4096):
         """(int32 [cap,2] device buffer of (local row, cluster id) pairs, int32 [1] device count): one pair per grid
         cell that holds a core point with x_lo <= x < x_hi (pch_dbscan_strip_pairs_i32).  Asynchronous: the count
@@ -380,6 +393,11 @@ class DbscanFit:
             _lib.check(L.pch_dbscan_relabel_i32(_ptr(cmap), cmap.numel(), self.n, _ptr(self.labels),
                                                 _ptr(self.workspace), self.workspace.numel(), _stream()))
         return self.labels
+
+
+def set_pair_counting(enable):
+    """Counting variant of the radius-count kernel for the fits this thread makes from now on (measurement only)."""
+    _lib.lib().pch_dbscan_set_pair_counting(1 if enable else 0)
 
 
 def set_dbscan_sort_mode(mode):

@@ -167,7 +167,8 @@ def corridor_tile_torch(n_total, rank, world, halo, seed=SEED0, kind="corridor",
                         dtype=None):
     """This rank's part of the n_total-point strip corridor: its own strips (a consecutive file-order shard AND an
     x-tile) plus the rows of the two neighbouring strips within ``halo`` of its edges.  Nothing else of the cloud
-    is generated.  Returns dict(points [n_t,3] (float64 or dtype) in file order, own bool [n_t], local_row int64
+    is generated.  Returns dict(points [n_t,3] (float64 or dtype) in file order, own bool [n_t] (= the rows
+    own_range[0] <= i < own_range[1]: left halo | own | right halo), local_row int64
     [n_t] (row relative to the first OWNED row: negative in the left halo, >= n_own in the right halo), n_own,
     x_lo, x_hi (tile edges in the frame of ``points``), strips (a, b)).  Global rows = local_row + the exclusive
     prefix of n_own over the ranks (tiles.global_rows)."""
@@ -205,5 +206,7 @@ def corridor_tile_torch(n_total, rank, world, halo, seed=SEED0, kind="corridor",
     if dtype is not None:
         parts = [p.to(dtype) for p in parts]
     pts = torch.cat(parts, dim=0).contiguous()
-    return dict(points=pts, own=torch.cat(own), local_row=torch.cat(local), n_own=int(n_own), x_lo=lo, x_hi=hi,
-                strips=(a, b))
+    own = torch.cat(own)
+    n_left = int(parts[0].shape[0]) if a > 0 else 0
+    return dict(points=pts, own=own, own_range=(n_left, n_left + int(n_own)), local_row=torch.cat(local),
+                n_own=int(n_own), x_lo=lo, x_hi=hi, strips=(a, b))

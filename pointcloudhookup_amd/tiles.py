@@ -479,10 +479,11 @@ def shared_percentile(values, q_percent, sub=None, select=None, group=None):
 class HipMeanShard:
     """the per-rank part of the chained float32 column sums on the GPU (ops.MeanShard: tables first, walk later)"""
 
-    def __init__(self, rows):
+    def __init__(self, rows, want_zcol=False):
         from . import ops
-        self._sh = ops.MeanShard(rows)
+        self._sh = ops.MeanShard(rows, want_zcol=want_zcol)
         self.device = self._sh.device
+        self.zcol = self._sh.zcol
 
     def walk(self, sum_in, total_n):
         return self._sh.walk(sum_in, total_n)
@@ -544,8 +545,8 @@ def tiled_step(tile, tile_rows, own, total_n, x_lo, x_hi, eps=8.0, min_samples=8
 
     tile      : float32 [n_t,3] device tensor, this rank's rows (halo included) in file order
     tile_rows : int64 [n_t] global row of every tile row, ascending
-    own       : bool [n_t], the rows this rank owns; over the ranks the owned rows are the consecutive blocks
-                [base_r, base_r + n_r) of the cloud, in rank order
+    own       : (a, b): the tile rows [a, b) are the ones this rank owns (left halo | own | right halo); over the
+                ranks the owned rows are the consecutive blocks [base_r, base_r + n_r) of the cloud, in rank order
     total_n   : rows of the whole cloud
     x_lo, x_hi: this rank's own x-range in the RAW frame (the tile edges)
     Returns dict(centroid f32[3], threshold f32, used_fallback, points (kept, centred, halo included), rows (global),
@@ -559,12 +560,13 @@ def tiled_step(tile, tile_rows, own, total_n, x_lo, x_hi, eps=8.0, min_samples=8
     import time
     from . import ops
     t0 = time.perf_counter()
-    own_idx = torch.nonzero(own).flatten()
-    own_rows = tile[own_idx] if own_idx.numel() != tile.shape[0] else tile
+    a, b = int(own[0]), int(own[1])
+    own_rows = tile[a:b]                                   # a view: the owned rows are one slice of the tile
     _mark(timings, "start")
-    centroid = sharded_centroid(own_rows.contiguous(), total_n, group=group, timings=timings)
+    shard = HipMeanShard(own_rows, want_zcol=True)         # tables + a contiguous z column in one pass over the rows
+    centroid = sharded_centroid(own_rows, total_n, shard=shard, group=group, timings=timings)
     _mark(timings, "centroid")
-    base = shared_percentile(own_rows[:, 2], pct, sub=centroid[2], group=group)
+    base = shared_percentile(shard.zcol, pct, sub=centroid[2], group=group)
     _mark(timings, "percentile")
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
@@ -572,7 +574,7 @@ def tiled_step(tile, tile_rows, own, total_n, x_lo, x_hi, eps=8.0, min_samples=8
         thr = np.float32(base + np.float32(off))
         kept = ops.filter_gt(tile, centroid, thr, want_index=True)
         loc = kept["index"].long()
-        own_k = own[loc]
+        own_k = (loc >= a) & (loc < b)
         cnt = torch.tensor([int(own_k.sum())], dtype=torch.int64)
         if multi:
             if dist.get_backend(group) == "nccl":
