@@ -293,6 +293,8 @@ def main():
                     help="skip the two-tiles-in-flight side measurement (profiling runs)")
     ap.add_argument("--no-side", action="store_true",
                     help="skip every side measurement (voxel stage, other workloads): profiling runs")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the 100 M-point LAS file run through the drop-ins")
+    ap.add_argument("--e2e-points", type=int, default=100_000_000)
     ap.add_argument("--las", default=None,
                     help="BASELINE config 5: a real .las file run end to end through the drop-in modules "
                          "(voxel downsample -> extract_towers); reported as a side value, 'skipped' without a file")
@@ -654,6 +656,68 @@ def main():
         except Exception as e:
             out.setdefault("voxel_stage", {"error": str(e)})
             out["dropin_end_to_end"] = {"error": str(e)}
+
+    # ---- the drop-ins end to end at the HEADLINE size and the GUI's own settings (voxel 0.1 m, 500 000-row chunks:
+    # pyGUI_towers_test.py:351-358): a 100 M-point format-3 LAS file (3.4 GB, warm page cache) through
+    # run_voxel_downsampling, then extract_towers on its output, each with a per-stage wall-clock table
+    if world == 1 and not args.no_side and not args.no_e2e:
+        try:
+            import shutil
+            import tempfile
+            from pointcloudhookup_amd import las as _las, stages as _stages
+            from pointcloudhookup_amd.ui import import_PC as _imp
+            from pointcloudhookup_amd.utils import tower_extraction as _te
+            ne = int(args.e2e_points)
+            td = tempfile.mkdtemp(prefix="pch_e2e_")
+            try:
+                if shutil.disk_usage(td).free < 8 * 34 * ne // 4:
+                    raise RuntimeError(f"not enough free space under {td}")
+                sc, of = np.array([0.001, 0.001, 0.001]), np.array([437000.0, 3139000.0, 0.0])
+                src = os.path.join(td, "cloud.las")
+                xyz64 = synth.corridor_torch(ne, seed=synth.SEED0 + 5, kind="corridor", offset=True, device=dev)
+                ints = ops.las_unscale(xyz64, sc, of)
+                del xyz64
+                t0 = time.perf_counter()
+                _las.write_device(src, _las.LasHeader(point_format=3, version=(1, 2), scales=sc, offsets=of), ints)
+                t_write_src = time.perf_counter() - t0
+                del ints
+                torch.cuda.empty_cache()
+                size_in = os.path.getsize(src)
+                cwd = os.getcwd()
+                os.chdir(td)
+                _stages.enable(True)
+                try:
+                    out_las = os.path.join(td, "output", "point_2.las")
+                    t0 = time.perf_counter()
+                    _imp.run_voxel_downsampling(src, out_las, 0.1, 500000)
+                    t1 = time.perf_counter()
+                    tw = _te.extract_towers(out_las, log_callback=lambda m: None)
+                    t2 = time.perf_counter()
+                finally:
+                    _stages.enable(False)
+                    os.chdir(cwd)
+                size_mid = os.path.getsize(out_las)
+                hv = _las.read_header_native(out_las)
+                sv = {k: round(v, 4) for k, v in (_stages.last("run_voxel_downsampling") or {}).items()}
+                se = {k: round(v, 4) for k, v in (_stages.last("extract_towers") or {}).items()}
+                rd = sv.get("read LAS -> device int32 (file, H2D, decode)")
+                out["dropin_end_to_end_100m"] = {
+                    "points_in": ne, "las_bytes_in": size_in, "voxel": 0.1, "chunk": 500000,
+                    "voxels_out": int(hv.point_count), "las_bytes_between": size_mid, "towers": len(tw),
+                    "run_voxel_downsampling_s": round(t1 - t0, 3), "extract_towers_s": round(t2 - t1, 3),
+                    "Mpts_per_s_file_to_dicts": round(ne / (t2 - t0) / 1e6, 1),
+                    "Mpts_per_s_extract_towers_on_its_input": round(int(hv.point_count) / (t2 - t1) / 1e6, 1),
+                    "stages_run_voxel_downsampling_s": sv, "stages_extract_towers_s": se,
+                    "read_GBps": round(size_in / rd / 1e9, 2) if rd else None,
+                    "source_file_write_GBps": round(size_in / t_write_src / 1e9, 2),
+                    "las_io_threads": os.environ.get("PCH_LAS_THREADS", "default (8 when >= 16 cores)"),
+                    "note": "wall clock with stage timers on (the device is drained at every stage edge); page cache "
+                            "warm (the file was just written); LAS reader: pread by several threads -> pinned ring -> "
+                            "H2D || decode; writer: records laid out on the device, pwrite by several threads"}
+            finally:
+                shutil.rmtree(td, ignore_errors=True)
+        except Exception as e:
+            out["dropin_end_to_end_100m"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- BASELINE config 5: a real .las through the drop-ins
     if world == 1:

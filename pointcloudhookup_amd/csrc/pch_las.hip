@@ -1,6 +1,7 @@
 // Native LAS 1.0-1.4 point I/O for the hot path: header parse, X/Y/Z int32 of every point record
-// straight into a device buffer (mmap -> pinned double buffer -> H2D copy overlapped with the decode
-// kernel), and the writer the drop-ins use for their output clouds.
+// straight into a device buffer (pread by several threads -> ring of pinned buffers -> H2D copy overlapped with the
+// decode kernel), and the writer the drop-ins use for their output clouds (records laid out on the device, pwrite by
+// several threads).
 // Replaces: laspy.read / laspy.open(...).read() (ui/import_PC.py:28, utils/tower_extraction.py:60-61,
 //           ui/extract.py:114-115) and LasData.write (ui/import_PC.py:35-42,64-65,
 //           utils/tower_extraction.py:243-257).  Only what those call sites touch is implemented: the
@@ -14,7 +15,11 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <stdlib.h>
+
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace pch {
@@ -116,27 +121,122 @@ __global__ void las_decode_k(const uint8_t* __restrict__ rec, int64_t count3, in
     out[e] = (int32_t)v;
 }
 
-constexpr size_t LAS_HOP = size_t(32) << 20;        // bytes of point records per pinned buffer
+constexpr size_t LAS_HOP = size_t(64) << 20;        // bytes of point records per pinned buffer
+constexpr int    LAS_RING = 3;                      // pinned buffers in flight (file -> pinned -> device)
 
-struct Pinned2 {
-    void* buf[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
+// Pinned staging buffers, kept per thread and device across calls (pinning 192 MiB costs tens of ms - as much
+// as reading a 10 M-point file); never released from the main thread's destructors (may_release_hip_objects).
+struct PinnedRing {
+    void* buf[LAS_RING] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[LAS_RING] = {nullptr, nullptr, nullptr};
     bool ok = false;
-    int init(size_t bytes) {
-        for (int k = 0; k < 2; ++k) {
-            PCH_HIP_TRY(hipHostMalloc(&buf[k], bytes, hipHostMallocDefault));
+    int init() {
+        if (ok) return PCH_OK;
+        for (int k = 0; k < LAS_RING; ++k) {
+            PCH_HIP_TRY(hipHostMalloc(&buf[k], LAS_HOP, hipHostMallocDefault));
             PCH_HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
         }
         ok = true;
         return PCH_OK;
     }
-    ~Pinned2() {
-        for (int k = 0; k < 2; ++k) {
+    ~PinnedRing() {
+        if (!may_release_hip_objects()) return;
+        for (int k = 0; k < LAS_RING; ++k) {
             if (ev[k]) (void)hipEventDestroy(ev[k]);
             if (buf[k]) (void)hipHostFree(buf[k]);
         }
     }
 };
+struct PinnedRings { PinnedRing r[PCH_MAX_DEVICES]; };
+static PinnedRing& pinned_ring() {
+    static thread_local PinnedRings all;
+    return all.r[current_device_slot()];
+}
+
+// host threads that move file bytes (page cache <-> pinned memory): one thread tops out near 2-4 GB/s of
+// pread / pwrite, a PCIe Gen5 link takes ~50 GB/s.  PCH_LAS_THREADS overrides (1 = the calling thread only).
+static int las_io_threads() {
+    static int n = -1;
+    if (n < 0) {
+        const char* e = getenv("PCH_LAS_THREADS");
+        int v = e ? atoi(e) : 0;
+        if (v <= 0) {
+            const unsigned hw = std::thread::hardware_concurrency();
+            v = hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1);
+        }
+        n = v > 32 ? 32 : v;
+    }
+    return n;
+}
+
+// pread / pwrite of [off, off+bytes) split into slices, one per thread; returns false on a short transfer
+template <bool WRITE>
+static bool las_file_io(int fd, unsigned char* mem, size_t bytes, off_t off) {
+    auto one = [&](size_t a, size_t b) -> bool {
+        while (a < b) {
+            const ssize_t r = WRITE ? ::pwrite(fd, mem + a, b - a, off + (off_t)a) : ::pread(fd, mem + a, b - a, off + (off_t)a);
+            if (r <= 0) { if (r < 0 && errno == EINTR) continue; return false; }
+            a += (size_t)r;
+        }
+        return true;
+    };
+    int nt = las_io_threads();
+    if (bytes < (size_t(4) << 20)) nt = 1;
+    if (nt <= 1) return one(0, bytes);
+    std::atomic<bool> good{true};
+    std::vector<std::thread> th;
+    const size_t slice = ((bytes + nt - 1) / nt + 4095) & ~size_t(4095);
+    for (int t = 1; t < nt; ++t) {
+        const size_t a = (size_t)t * slice, b = a + slice < bytes ? a + slice : bytes;
+        if (a >= bytes) break;
+        th.emplace_back([&, a, b] { if (!one(a, b)) good.store(false); });
+    }
+    if (!one(0, slice < bytes ? slice : bytes)) good.store(false);
+    for (auto& t : th) t.join();
+    return good.load();
+}
+
+// records of `count` points laid out for the file: X,Y,Z at the head of every record_len-byte record, every other
+// byte zero (what laspy writes for a LasData whose only assigned dimensions are x, y, z); one thread per 4 bytes
+__global__ void las_encode_k(const int32_t* __restrict__ XYZ, int64_t count, int record_len,
+                             uint8_t* __restrict__ out) {
+    const int64_t total = count * record_len;
+    const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (b >= total) return;
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t at = b + k;
+        if (at >= total) break;
+        const int64_t i = at / record_len;
+        const int o = (int)(at - i * record_len);
+        if (o < 12) w |= (uint32_t)((((uint32_t)XYZ[3 * i + (o >> 2)]) >> (8 * (o & 3))) & 0xFFu) << (8 * k);
+    }
+    if (b + 4 <= total) *reinterpret_cast<uint32_t*>(out + b) = w;
+    else for (int k = 0; b + k < total; ++k) out[b + k] = (uint8_t)(w >> (8 * k));
+}
+
+// bounding box of the integer coordinates: [0..2] minima, [3..5] maxima (int32, pre-set to +max / -max)
+__global__ void las_minmax_k(const int32_t* __restrict__ XYZ, int64_t n, int32_t* __restrict__ box) {
+    int32_t lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int32_t v = XYZ[3 * i + a];
+            lo[a] = v < lo[a] ? v : lo[a];
+            hi[a] = v > hi[a] ? v : hi[a];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = wave_reduce_min(lo[a]);
+        hi[a] = wave_reduce_max(hi[a]);
+    }
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { atomicMin(&box[a], lo[a]); atomicMax(&box[3 + a], hi[a]); }
+    }
+}
 
 }  // namespace pch
 
@@ -166,23 +266,29 @@ extern "C" int pch_las_read_xyz_i32(const char* path, int64_t first, int64_t cou
     const size_t rl = h.record_length;
     const int64_t per_hop = (int64_t)(LAS_HOP / rl);
     uint8_t* dev[2] = {static_cast<uint8_t*>(ws), static_cast<uint8_t*>(ws) + LAS_HOP + 256};
-    Pinned2 pin;
-    PCH_TRY(pin.init(LAS_HOP));
-    const unsigned char* recs = f.map + h.offset_to_points + (size_t)first * rl;
-    int k = 0;
-    for (int64_t done = 0; done < count; done += per_hop, k ^= 1) {
+    PinnedRing& pin = pinned_ring();
+    PCH_TRY(pin.init());
+    // file -> pinned buffer (pread, several threads) -> device buffer (H2D) -> decode kernel.  Three pinned buffers
+    // and two device buffers: while the threads fill hop k+1, hop k crosses PCIe and hop k-1 is decoded.
+    // (the two device buffers need no events: copy and decode of a hop are ordered on the one stream)
+    const off_t base = (off_t)h.offset_to_points + (off_t)first * (off_t)rl;
+    int64_t hop = 0;
+    for (int64_t done = 0; done < count; done += per_hop, ++hop) {
         const int64_t m = (count - done) < per_hop ? (count - done) : per_hop;
         const size_t bytes = (size_t)m * rl;
-        // the pinned buffer is free again once the copy that last read it has finished; meanwhile the
-        // GPU is busy with the previous hop's copy + decode
-        PCH_HIP_TRY(hipEventSynchronize(pin.ev[k]));
-        memcpy(pin.buf[k], recs + (size_t)done * rl, bytes);           // page cache / disk -> pinned
-        PCH_HIP_TRY(hipMemcpyAsync(dev[k], pin.buf[k], bytes, hipMemcpyHostToDevice, s));
-        PCH_HIP_TRY(hipEventRecord(pin.ev[k], s));
+        const int p = (int)(hop % LAS_RING), d = (int)(hop & 1);
+        PCH_HIP_TRY(hipEventSynchronize(pin.ev[p]));        // the copy that last read this pinned buffer is done
+        if (!las_file_io<false>(f.fd, static_cast<unsigned char*>(pin.buf[p]), bytes, base + (off_t)done * (off_t)rl)) {
+            set_error("%s: short read of the point records: %s", path, strerror(errno));
+            (void)hipStreamSynchronize(s);
+            return PCH_ERR_ARG;
+        }
+        PCH_HIP_TRY(hipMemcpyAsync(dev[d], pin.buf[p], bytes, hipMemcpyHostToDevice, s));
+        PCH_HIP_TRY(hipEventRecord(pin.ev[p], s));
         PCH_LAUNCH("las_decode", las_decode_k, dim3((unsigned)ceil_div(3 * m, 256)), dim3(256), 0, s,
-                   (const uint8_t*)dev[k], 3 * m, (int)rl, out_XYZ + 3 * done);
+                   (const uint8_t*)dev[d], 3 * m, (int)rl, out_XYZ + 3 * done);
     }
-    PCH_HIP_TRY(hipStreamSynchronize(s));               // the pinned buffers and the mapping go away on return
+    PCH_HIP_TRY(hipStreamSynchronize(s));               // the mapping goes away on return
     return PCH_OK;
 }
 
@@ -205,41 +311,52 @@ extern "C" int pch_las_write_xyz_i32(const char* path, const PchLasHeader* hdr, 
     if (::write(fd, head.data(), head.size()) != (ssize_t)head.size()) { set_error("%s: write failed", path); return PCH_ERR_ARG; }
     int32_t lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
     if (n > 0) {
-        const int64_t per_hop = (int64_t)(LAS_HOP / 12);
-        Pinned2 pin;
-        PCH_TRY(pin.init((size_t)per_hop * 12));
-        std::vector<unsigned char> out((size_t)per_hop * rl);
-        // D2H of hop k+1 runs while hop k is laid out and written
+        // The DEVICE lays the records out (las_encode_k) and reduces the bounding box (las_minmax_k); the host only
+        // moves finished bytes: D2H into pinned buffers, pwrite from several threads.  Hop k+1 is encoded and copied
+        // while hop k is written.
+        const int64_t per_hop = (int64_t)(LAS_HOP / rl);
+        PinnedRing& pin = pinned_ring();
+        PCH_TRY(pin.init());
+        uint8_t* enc[2] = {nullptr, nullptr};
+        int32_t* box = nullptr;
+        struct DevGuard { uint8_t** e; int32_t** b; ~DevGuard() { for (int k = 0; k < 2; ++k) if (e[k]) (void)hipFree(e[k]); if (*b) (void)hipFree(*b); } } dg{enc, &box};
+        for (int k = 0; k < 2; ++k) PCH_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&enc[k]), (size_t)per_hop * rl + 16));
+        PCH_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&box), 6 * sizeof(int32_t)));
+        const int32_t init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
+        PCH_HIP_TRY(hipStreamSynchronize(s));                // XYZ is final; the blocking copy below is then ordered
+        PCH_HIP_TRY(hipMemcpy(box, init, sizeof(init), hipMemcpyHostToDevice));
+        {
+            int64_t gb = ceil_div(n, 256 * 8);
+            if (gb > 4096) gb = 4096;
+            PCH_LAUNCH("las_minmax", las_minmax_k, dim3((unsigned)gb), dim3(256), 0, s, XYZ, n, box);
+        }
+        int32_t host_box[6];
+        PCH_TRY(peek_enqueue(box, sizeof(host_box), s));     // lands in the pinned peek buffer, fetched after the hops
         const int64_t hops = ceil_div(n, per_hop);
         auto start = [&](int64_t hop) -> int {
             const int64_t at = hop * per_hop, m = (n - at) < per_hop ? (n - at) : per_hop;
-            PCH_HIP_TRY(hipMemcpyAsync(pin.buf[hop & 1], XYZ + 3 * at, (size_t)m * 12, hipMemcpyDeviceToHost, s));
-            PCH_HIP_TRY(hipEventRecord(pin.ev[hop & 1], s));
+            const int p = (int)(hop % 2);
+            PCH_LAUNCH("las_encode", las_encode_k, dim3((unsigned)ceil_div(ceil_div(m * rl, 4), 256)), dim3(256), 0, s,
+                       XYZ + 3 * at, m, rl, enc[p]);
+            PCH_HIP_TRY(hipMemcpyAsync(pin.buf[p], enc[p], (size_t)m * rl, hipMemcpyDeviceToHost, s));
+            PCH_HIP_TRY(hipEventRecord(pin.ev[p], s));
             return PCH_OK;
         };
         PCH_TRY(start(0));
         for (int64_t hop = 0; hop < hops; ++hop) {
-            if (hop + 1 < hops) PCH_TRY(start(hop + 1));
-            PCH_HIP_TRY(hipEventSynchronize(pin.ev[hop & 1]));
+            if (hop + 1 < hops) PCH_TRY(start(hop + 1));       // buffer (hop+1)%2 was written out in the round before
+            PCH_HIP_TRY(hipEventSynchronize(pin.ev[hop % 2]));
             const int64_t at = hop * per_hop, m = (n - at) < per_hop ? (n - at) : per_hop;
-            const int32_t* src = static_cast<const int32_t*>(pin.buf[hop & 1]);
-            memset(out.data(), 0, (size_t)m * rl);
-            for (int64_t i = 0; i < m; ++i) {
-                memcpy(out.data() + (size_t)i * rl, src + 3 * i, 12);
-                for (int a = 0; a < 3; ++a) {
-                    const int32_t v = src[3 * i + a];
-                    lo[a] = v < lo[a] ? v : lo[a];
-                    hi[a] = v > hi[a] ? v : hi[a];
-                }
-            }
-            size_t off = 0;
-            const size_t total = (size_t)m * rl;
-            while (off < total) {
-                const ssize_t w = ::write(fd, out.data() + off, total - off);
-                if (w <= 0) { set_error("%s: write failed: %s", path, strerror(errno)); return PCH_ERR_ARG; }
-                off += (size_t)w;
+            if (!las_file_io<true>(fd, static_cast<unsigned char*>(pin.buf[hop % 2]), (size_t)m * rl,
+                                   (off_t)hs + (off_t)at * (off_t)rl)) {
+                set_error("%s: write failed: %s", path, strerror(errno));
+                (void)hipStreamSynchronize(s);
+                return PCH_ERR_ARG;
             }
         }
+        PCH_HIP_TRY(hipStreamSynchronize(s));
+        PCH_TRY(peek_wait(host_box, sizeof(host_box)));
+        for (int a = 0; a < 3; ++a) { lo[a] = host_box[a]; hi[a] = host_box[3 + a]; }
     }
     // ---- public header block
     unsigned char* h = head.data();

@@ -46,11 +46,13 @@ def run_voxel_downsampling(
 
     import torch
     from .. import las as _las
-    from .. import ops
+    from .. import ops, stages
 
+    clock = stages.Clock("run_voxel_downsampling")
     dev = torch.device(DEVICE)
     hdr, XYZ = _las.read_device(input_path, dev)                      # records decoded on the GPU
     total_points = int(XYZ.shape[0])
+    clock.mark("read LAS -> device int32 (file, H2D, decode)")
 
     if log_callback:
         log_callback(f"📂 原始点数: {total_points}")
@@ -59,11 +61,14 @@ def run_voxel_downsampling(
     if total_points:
         xyz = ops.las_scale(XYZ, hdr.scales, hdr.offsets)            # chunk.x/.y/.z  (:47-48)
         del XYZ
+        clock.mark("int32 -> float64 scaled view")
         _, mean, _, offs = ops.voxel_downsample(xyz, float(voxel_size), int(chunk_size))
         del xyz
+        clock.mark("voxel grids (all chunks)")
         out_XYZ = ops.las_unscale(mean, hdr.scales, hdr.offsets)                 # :61-63
         n_out = int(mean.shape[0])
         del mean
+        clock.mark("float64 -> int32")
     else:
         out_XYZ = torch.zeros((0, 3), dtype=torch.int32, device=dev)
         n_out = 0
@@ -76,8 +81,10 @@ def run_voxel_downsampling(
         if progress_callback:
             progress_callback(int((end / total_points) * 100))
 
+    clock.mark("per-chunk callbacks")
     _las.write_device(output_path, _las.LasHeader(point_format=hdr.point_format, version=hdr.version,
                                                   scales=hdr.scales, offsets=hdr.offsets), out_XYZ)
+    clock.mark("write LAS (encode, D2H, file)")
     ops.release_workspace()
 
     if log_callback:

@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import os
 import sys
+import time
 from pathlib import Path
 
 import numpy as np
@@ -70,14 +71,17 @@ def extract_towers(
         progress(5)
         import torch
         from .. import las as _las
-        from .. import ops, pipeline
+        from .. import ops, pipeline, stages
+        clock = stages.Clock("extract_towers")
         if os.path.getsize(input_las_path) >= PRESTART_BYTES:
             from .. import obb as _obb
             _obb.prestart()                # the box workers import scipy while the file is being read
         dev = torch.device(DEVICE)
         hdr, XYZ = _las.read_device(input_las_path, dev)               # records decoded on the GPU
+        clock.mark("read LAS -> device int32 (file, H2D, decode)")
         raw = ops.cast_f32(ops.las_scale(XYZ, hdr.scales, hdr.offsets))
         del XYZ
+        clock.mark("int32 -> float64 -> float32")
         header_info = {"scales": hdr.scales, "offsets": hdr.offsets,
                        "point_format": hdr.point_format, "version": hdr.version}
         log(f"✅ 点云读取完成，总点数: {raw.shape[0]}")
@@ -92,6 +96,7 @@ def extract_towers(
         if raw.shape[0] == 0:
             raise IndexError("index -1 is out of bounds for axis 0 with size 0")
         gf = ops.ground_filter(raw, 25.0, 3.0, 1.0, 1000, want_index=False)
+        clock.mark("centroid + percentile filter")
         header_info["centroid"] = gf["centroid"]
         if gf["used_fallback"]:
             log(f"✅ 高度过滤完成，保留点数: {gf['count_at_offset']}")
@@ -114,8 +119,10 @@ def extract_towers(
     try:
         if n_f:
             labels, _, k = ops.dbscan(filtered, eps, min_points, CHUNK_SIZE, aabb=gf["aabb"])
+            clock.mark("chunked DBSCAN")
             perm, offsets, stats = ops.segment_by_label(labels, filtered, k)
             clusters.update(labels=labels, nclusters=k, perm=perm, offsets=offsets, stats=stats)
+            clock.mark("label grouping")
     except Exception as e:
         # all chunks run in one device pass, so a library error concerns all of them
         log(f"⚠️ 分块聚类失败（块0-{max(n_chunks - 1, 0)}）: {str(e)}")
@@ -135,6 +142,8 @@ def extract_towers(
     progress(75)
     centroid = gf["centroid"]
 
+    las_seconds = [0.0]
+
     def accept(t):
         label = t["label"]
         tower_obbs.append({"center": t["center"], "rotation": t["rotation"], "extent": t["extent"],
@@ -145,12 +154,17 @@ def extract_towers(
                            "北方向偏角": t["north_angle"], "宽度": t["width"],
                            "长宽比": t["aspect_ratio"]})
         original_points = t["points"] + centroid                       # float32, reference :205
+        t_las = time.perf_counter()
         _save_tower_las(original_points, None, header_info, output_dir / f"tower_{label}.las", log)
+        las_seconds[0] += time.perf_counter() - t_las
         log(f"✅ 杆塔{label}: {t['height']:.1f}m高 | {t['width']:.1f}m宽 | 中心坐标{t['center']}")
         progress(75 + int(15 * (label + 1) / max(k, 1)))
 
+    clock.mark("per-chunk callbacks")
     pipeline.tower_table(clusters, aspect_ratio_threshold, min_height, max_width, min_width,
                          duplicate_threshold, OBB_EXTENT_ORDER, log=log, on_accept=accept, obb_mode=OBB_MODE)
+    clock.mark("tower boxes + accept / de-dup (D1-D3)")
+    clock.move("tower boxes + accept / de-dup (D1-D3)", "per-tower LAS files", las_seconds[0])
 
     # ---- xlsx (reference :221-231)
     if tower_rows:
@@ -165,6 +179,7 @@ def extract_towers(
     else:
         log("\n⚠️ 未检测到任何杆塔，不生成Excel文件")
 
+    clock.mark("xlsx", sync=False)
     log("\n=== 清理内存 ===")
     del filtered, clusters, gf
     ops.release_workspace()

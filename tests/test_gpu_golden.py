@@ -164,11 +164,21 @@ def test_dropin_chunk_failure_like_reference(cuda, tmp_path, monkeypatch):
             assert logs[:len(ref_logs) - 1] == ref_logs[:-1] and logs[-1] == "✅ 杆塔提取完成" and prog[-1] == 100
 
 
-@pytest.mark.parametrize("case", ["config1_1m", "towers5x3", "fallback"])
+_FAST_KNOWN_MISS = ("towers5x3",)
+
+
+@pytest.mark.parametrize("case", [
+    "config1_1m",
+    pytest.param("towers5x3", marks=pytest.mark.xfail(strict=True, reason=(
+        "opt-in fast OBB mode: qhull lists the facets of the device-filtered cluster in another order, trimesh's "
+        "'first normal per 0.1 rad bucket' rule then picks other candidates, one box comes out centimetres apart and "
+        "flips the size filter - fast mode accepts 2 towers where the reference run accepts 1.  A parity failure of "
+        "that mode (DESIGN.md section 11), which is why exact mode is the default"))),
+    "fallback"])
 def test_dropin_fast_obb_mode_on_reference_run(cuda, case, tmp_path, monkeypatch, capsys):
-    """PCH_OBB_MODE=fast on the reference-run fixtures: same towers, same points; the centre / extent deltas
-    against the reference run are printed per fixture (the mode is opt-in because qhull may list the facets of
-    the pre-filtered cluster in another order - DESIGN.md section 11)."""
+    """PCH_OBB_MODE=fast on the reference-run fixtures must give the reference run's towers: the same NUMBER of
+    towers, the same points, centres within the north star's 1e-3 m.  Where it does not, the case is marked
+    xfail(strict) with the reason - the assertion is not widened."""
     from pointcloudhookup_amd.utils import tower_extraction as te
     g, x, y, z, XYZ, kwargs = _load(case)
     path = str(tmp_path / "cloud.las")
@@ -177,20 +187,10 @@ def test_dropin_fast_obb_mode_on_reference_run(cuda, case, tmp_path, monkeypatch
     monkeypatch.setattr(te, "OBB_MODE", "fast")
     towers = te.extract_towers(path, log_callback=lambda m: None, **kwargs)
     n = len(g["unsorted_center"])
-    # pair every reference tower with the nearest fast-mode tower: a box that differs by centimetres can also flip
-    # the size filter (height / width / aspect thresholds), so the two lists need not have the same length
-    pairs = []
-    for i in range(n):
-        d = [float(np.abs(t["center"] - g["unsorted_center"][i]).max()) for t in towers]
-        if d and min(d) < 1.0:
-            pairs.append((i, int(np.argmin(d))))
-    dc = [float(np.abs(towers[j]["center"] - g["unsorted_center"][i]).max()) for i, j in pairs]
-    de = [float(np.abs(np.asarray(towers[j]["extent"]) - g["unsorted_extent"][i]).max()) for i, j in pairs]
     with capsys.disabled():
-        print(f"\n[fast OBB vs reference run, {case}] towers: reference {n}, fast {len(towers)}, paired {len(pairs)}; "
-              f"centre delta max {max(dc, default=0):.2e} m, extent delta max {max(de, default=0):.2e} m, "
-              f"centres within 1e-3 m: {sum(d <= 1e-3 for d in dc)}/{len(pairs)}")
-    assert len(pairs) == n and abs(len(towers) - n) <= 2
-    for (i, j), c, e in zip(pairs, dc, de):
-        assert _sha(towers[j]["points"]) == str(g["unsorted_points_sha"][i])
-        assert c < 0.05 and e < 0.1
+        print(f"\n[fast OBB vs reference run, {case}] towers: reference {n}, fast {len(towers)}")
+    assert len(towers) == n
+    for i, t in enumerate(towers):
+        assert _sha(t["points"]) == str(g["unsorted_points_sha"][i])
+        assert float(np.abs(t["center"] - g["unsorted_center"][i]).max()) <= 1e-3
+        assert float(np.abs(np.asarray(t["extent"]) - g["unsorted_extent"][i]).max()) <= 1e-3

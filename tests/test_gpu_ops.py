@@ -494,7 +494,8 @@ def test_count_at_offset_is_an_integer_above_2_pow_24(cuda):
 def test_native_las_reader_on_byte_built_files(cuda, tmp_path):
     """pch_las_read_xyz_i32 against files assembled from the LAS specification in tests/las_bytes.py (not by
     our own writer): VLRs, padding in front of the point data, extra bytes, odd record lengths (misaligned
-    X/Y/Z), LAS 1.4 with the 64-bit count only, and a file larger than one 32 MiB hop of the pinned buffer."""
+    X/Y/Z), LAS 1.4 with the 64-bit count only, and a file of four 64 MiB hops (the ring of three pinned buffers
+    wraps around; every hop is read by several threads with pread)."""
     import las_bytes
     from pointcloudhookup_amd import las
     rng = np.random.default_rng(5)
@@ -503,7 +504,7 @@ def test_native_las_reader_on_byte_built_files(cuda, tmp_path):
              dict(n=4097, point_format=1, version=(1, 3), extra_bytes=5),
              dict(n=5000, point_format=6, version=(1, 4), vlr_payloads=(b"z" * 100,), extra_bytes=3),
              dict(n=0, point_format=0, version=(1, 2)),
-             dict(n=1_300_000, point_format=7, version=(1, 4), extra_bytes=1)]      # 37-byte records, 2 hops
+             dict(n=5_500_000, point_format=7, version=(1, 4), extra_bytes=1)]      # 37-byte records, 4 hops
     for i, kw in enumerate(cases):
         n = kw.pop("n")
         XYZ = rng.integers(-2**31, 2**31 - 1, size=(n, 3), dtype=np.int64).astype(np.int32)
@@ -519,7 +520,10 @@ def test_native_las_writer_roundtrip_and_layout(cuda, tmp_path):
     import las_bytes
     from pointcloudhookup_amd import las
     rng = np.random.default_rng(6)
-    for n, fmt, ver in ((0, 3, (1, 2)), (1, 0, (1, 2)), (5000, 3, (1, 2)), (3_000_000, 1, (1, 3)), (1234, 6, (1, 4))):
+    # 7.5 M x 28 B = 210 MB: four hops (records laid out on the device, pwrite by several threads); 26-byte records
+    # (format 2) are not a multiple of 4: the last word of a hop is written byte by byte
+    for n, fmt, ver in ((0, 3, (1, 2)), (1, 0, (1, 2)), (5000, 3, (1, 2)), (7_500_000, 1, (1, 3)), (1234, 6, (1, 4)),
+                        (333_331, 2, (1, 2))):
         XYZ = rng.integers(-10**9, 10**9, size=(n, 3), dtype=np.int64).astype(np.int32)
         p = str(tmp_path / f"w{n}.las")
         hdr = las.LasHeader(point_format=fmt, version=ver, scales=np.array([0.001, 0.002, 0.01]),
