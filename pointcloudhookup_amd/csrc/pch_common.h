@@ -108,10 +108,18 @@ int peek_enqueue(const void* dev, size_t bytes, hipStream_t s);
 // wait for the copy, then memcpy to dst
 int peek_wait(void* dst, size_t bytes);
 
-// stage C with an early host copy of the cluster count (pch_dbscan.hip); k_host may be null
+// By-product of stage C for the grouping stage (D0): per-cluster bounding boxes accumulated by the kernels that
+// make the labels.  acc: [cap][8] uint32 (device; zeroed by the run), row k = {max ~ordered(min xyz), max ordered(max
+// xyz), 0, 0} - decoded in place by the grouping stage (segment_run, stats_encoded).  done: set by the run when the
+// table was filled (not on the per-chunk fallback for grids beyond the 64-bit key).
+struct DbBoxOut { uint32_t* acc; int32_t cap; bool done; };
+// stage C with an early host copy of the cluster count (pch_dbscan.hip); k_host and box may be null
 int dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples, int64_t chunk_size,
                const float* aabb_host, int32_t* labels, uint8_t* core, int32_t* out_nclusters,
-               void* ws, size_t ws_bytes, hipStream_t s, int32_t* k_host);
+               void* ws, size_t ws_bytes, hipStream_t s, int32_t* k_host, DbBoxOut* box = nullptr);
+// stage D0 (pch_segment.hip); stats_encoded: out_stats already holds the table a DbBoxOut run left there
+int segment_run(const int32_t* labels, const float* xyz, int64_t n, int32_t nclusters, int32_t* out_perm,
+                int64_t* out_offsets, float* out_stats, void* ws, size_t ws_bytes, hipStream_t s, bool stats_encoded);
 
 // ---------------------------------------------------------------- profiling
 // When enabled every PCH_LAUNCH is bracketed by hipEvents recorded on the launch stream.

@@ -589,7 +589,8 @@ __global__ __launch_bounds__(DB_THREADS) void db_cells_k(const uint64_t* __restr
                                                          uint32_t* __restrict__ cid,
                                                          uint32_t* __restrict__ cell_start,
                                                          uint64_t* __restrict__ cell_key,
-                                                         uint32_t* __restrict__ chunk_cells) {
+                                                         uint32_t* __restrict__ chunk_cells,
+                                                         uint32_t* __restrict__ cell_acc) {
     const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
     if (i >= n) return;
     const uint64_t key = keys[i], prev = i ? keys[i - 1] : 0;
@@ -599,6 +600,9 @@ __global__ __launch_bounds__(DB_THREADS) void db_cells_k(const uint64_t* __restr
     if (head) {
         cell_start[c] = (uint32_t)i;
         cell_key[c] = key;
+        uint4* a4 = reinterpret_cast<uint4*>(cell_acc + 8 * (int64_t)c);     // neutral start of db_cellstats_k
+        a4[0] = make_uint4(0u, 0u, 0u, 0u);
+        a4[1] = make_uint4(0u, 0u, 0u, 0u);
         const uint64_t ch = sh < 64 ? key >> sh : 0, pch = sh < 64 ? prev >> sh : 0;
         if (i == 0 || ch != pch) chunk_cells[ch] = c;      // every chunk holds rows, hence cells
     }
@@ -863,7 +867,12 @@ __device__ __forceinline__ void db_cellstats_flush(uint32_t* __restrict__ acc, u
 __global__ __launch_bounds__(DB_THREADS) void db_cellstats_k(const float4* __restrict__ pts,
                                                              const uint32_t* __restrict__ cid,
                                                              const uint8_t* __restrict__ core_s, int64_t n,
-                                                             uint32_t* __restrict__ acc) {
+                                                             uint32_t* __restrict__ acc,
+                                                             uint32_t* __restrict__ bits, int64_t nw) {
+    {   // the row bitmap db_mark_k sets bits in starts empty: n/32 words, and this grid has n/16 threads
+        const int64_t t = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
+        if (t < nw) bits[t] = 0u;
+    }
     const int64_t base = ((int64_t)blockIdx.x * DB_WAVES + wave_id()) * (64 * DB_CS_ROUNDS);
     if (base >= n) return;
     const int l = lane_id();
@@ -1374,14 +1383,37 @@ __global__ __launch_bounds__(DB_THREADS) void db_mark_k(const int* __restrict__ 
     }
 }
 
-// words of the row bitmap -> their population counts (the scan input)
-__global__ __launch_bounds__(DB_THREADS) void db_popc_k(const uint32_t* __restrict__ bits, int64_t nw,
-                                                        uint32_t* __restrict__ cnt) {
-    const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
-    if (i < nw) cnt[i] = (uint32_t)__popc(bits[i]);
+// Per-cluster bounding boxes, accumulated where the labels are made (the grouping stage then needs no pass of its
+// own over the points): acc[8 k + a], a = 0..2: max of ~ordered(x|y|z) (the minimum), a = 3..5: max of ordered(.)
+// - folded with atomicMax so that a zeroed table is the neutral start.  Points of a wave mostly share a label
+// (they are sorted by cell): one reduction + six atomics per label present in the wave.
+__device__ __forceinline__ void db_box_fold(uint32_t* __restrict__ acc, int32_t cap, int lab, const float4& p) {
+    const int l = lane_id();
+    const int mine = (lab >= 0 && lab < cap) ? lab : -1;
+    uint32_t k[3] = {f32_ordered(p.x), f32_ordered(p.y), f32_ordered(p.z)};
+    unsigned long long todo = __ballot(mine >= 0);
+    while (todo) {
+        const int lead = (int)__builtin_ctzll(todo);
+        const int L = __builtin_amdgcn_readlane(mine, lead);
+        const bool in = mine == L;
+        todo &= ~__ballot(in);
+        uint32_t v = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const uint32_t mn = wave_reduce_max(in ? ~k[a] : 0u);
+            const uint32_t mx = wave_reduce_max(in ? k[a] : 0u);
+            if (l == a) v = mn;
+            if (l == 3 + a) v = mx;
+        }
+        if (l < 6 && v) atomicMax(&acc[8 * (int64_t)L + l], v);
+    }
 }
 
-// labels of core points (original order), label of every cell, optional core mask
+// labels of core points (original order), label of every cell, optional core mask.
+// Block -> sorted range: with many chunks (bpc > 0) the blocks of one chunk share blockIdx % 8, i.e. one XCD and
+// one L2 (MI355X deals blocks round-robin over its 8 XCDs; a speed assumption only): the 4-byte label stores of a
+// chunk scatter over that chunk's own 200 KB window of `labels`, and lines written from several XCDs would leave
+// every L2 as partial lines.
 __global__ __launch_bounds__(DB_THREADS) void db_label_k(const float4* __restrict__ pts,
                                                          const uint32_t* __restrict__ cid,
                                                          const uint8_t* __restrict__ core_s,
@@ -1392,21 +1424,40 @@ __global__ __launch_bounds__(DB_THREADS) void db_label_k(const float4* __restric
                                                          const uint32_t* __restrict__ cell_start,
                                                          int* __restrict__ cell_label,
                                                          int32_t* __restrict__ labels,
-                                                         uint8_t* __restrict__ core_out) {
-    const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t c = cid[i];
-    const int r = root[c];
-    int lab = INT_BIG;
-    if (r >= 0) {                                          // clusters are numbered by their smallest core row
-        const uint32_t row = (uint32_t)comp_min[r];
-        lab = (int)(rank[row >> 5] + (uint32_t)__popc(bits[row >> 5] & ((1u << (row & 31u)) - 1u)));
+                                                         uint8_t* __restrict__ core_out, int64_t chunk_size, int bpc,
+                                                         int64_t nchunks, uint32_t* __restrict__ box_acc,
+                                                         int32_t box_cap) {
+    int64_t i;
+    bool valid;
+    if (bpc > 0) {
+        const int64_t slot = blockIdx.x >> 3;
+        const int64_t c = (slot / bpc) * 8 + (blockIdx.x & 7);
+        const int64_t within = (slot % bpc) * DB_THREADS + threadIdx.x;
+        i = c * chunk_size + within;
+        valid = c < nchunks && within < chunk_size && i < n;
+    } else {
+        i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
+        valid = i < n;
     }
-    const uint32_t o = __float_as_uint(pts[i].w);
-    const bool is_core = core_s[i] != 0;
-    labels[o] = is_core ? lab : -1;
-    if (core_out) core_out[o] = is_core ? 1 : 0;
-    if (cell_start[c] == (uint32_t)i) cell_label[c] = lab;
+    int lab = INT_BIG;
+    bool is_core = false;
+    float4 p;
+    p.x = p.y = p.z = p.w = 0.0f;
+    if (valid) {
+        const uint32_t c = cid[i];
+        const int r = root[c];
+        if (r >= 0) {                                      // clusters are numbered by their smallest core row
+            const uint32_t row = (uint32_t)comp_min[r];
+            lab = (int)(rank[row >> 5] + (uint32_t)__popc(bits[row >> 5] & ((1u << (row & 31u)) - 1u)));
+        }
+        p = pts[i];
+        const uint32_t o = __float_as_uint(p.w);
+        is_core = core_s[i] != 0;
+        labels[o] = is_core ? lab : -1;
+        if (core_out) core_out[o] = is_core ? 1 : 0;
+        if (cell_start[c] == (uint32_t)i) cell_label[c] = lab;
+    }
+    if (box_acc) db_box_fold(box_acc, box_cap, (valid && is_core && lab != INT_BIG) ? lab : -1, p);
 }
 
 // border points: smallest cluster id among the core points within eps
@@ -1418,7 +1469,8 @@ __global__ __launch_bounds__(DB_THREADS) void db_border_k(DbGrid g, const float4
                                                           const uint32_t* __restrict__ cell_ncore,
                                                           const float* __restrict__ cell_box,
                                                           const int* __restrict__ cell_label,
-                                                          int32_t* __restrict__ labels) {
+                                                          int32_t* __restrict__ labels,
+                                                          uint32_t* __restrict__ box_acc, int32_t box_cap) {
     __shared__ RowSet rows[DB_WAVES];
     const int A = blockIdx.x * DB_WAVES + wave_id();
     if (A >= m) return;
@@ -1455,6 +1507,11 @@ __global__ __launch_bounds__(DB_THREADS) void db_border_k(DbGrid g, const float4
             }
         }
         if (l == 0 && best != INT_BIG) labels[__float_as_uint(qp.w)] = best;
+        if (box_acc && best != INT_BIG && best >= 0 && best < box_cap && l < 6) {     // a border point joins its box
+            const float v = l % 3 == 0 ? qp.x : (l % 3 == 1 ? qp.y : qp.z);
+            const uint32_t k = f32_ordered(v);
+            atomicMax(&box_acc[8 * (int64_t)best + l], l < 3 ? ~k : k);
+        }
     }
 }
 
@@ -1539,8 +1596,12 @@ __global__ __launch_bounds__(DB_THREADS) void db_strip_pairs_k(const float4* __r
     }
 }
 
-__global__ void db_finish_k(const uint32_t* __restrict__ total, int32_t* __restrict__ out_nclusters) {
+// publishes the cluster count and zeroes the box accumulators (neutral start of db_box_fold)
+__global__ void db_prelabel_k(const uint32_t* __restrict__ total, int32_t* __restrict__ out_nclusters,
+                              uint32_t* __restrict__ box_acc, int64_t box_words) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *out_nclusters = (int32_t)*total;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (box_acc && i < box_words) box_acc[i] = 0u;
 }
 
 struct DbWs {
@@ -1564,10 +1625,10 @@ struct DbWs {
 
 static void db_plan(Arena& a, int64_t n, DbWs& w) {
     const int64_t nn = n > 0 ? n : 1;
-    w.meta = a.take<uint32_t>(16);
+    w.meta = a.take<uint32_t>(64);                       // exactly one 256-byte arena block ...
+    w.chunk_cells = a.take<uint32_t>(nn + 8);            // ... directly followed by this: ONE memset clears both
     w.core_stats = a.take<unsigned long long>(4);
     w.chunk_bad = a.take<uint32_t>(nn + 8);              // one word per chunk (chunk_size >= 1)
-    w.chunk_cells = a.take<uint32_t>(nn + 8);
     w.k0 = a.take<uint64_t>(nn);
     w.k1 = a.take<uint64_t>(nn);
     w.v0 = a.take<uint32_t>(nn);
@@ -1663,8 +1724,9 @@ extern "C" size_t pch_dbscan_ws_bytes(int64_t n) {
 
 int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples, int64_t chunk_size,
                     const float* aabb_host, int32_t* labels, uint8_t* core, int32_t* out_nclusters, void* ws,
-                    size_t ws_bytes, hipStream_t s, int32_t* k_host) {
+                    size_t ws_bytes, hipStream_t s, int32_t* k_host, DbBoxOut* boxes) {
     if (k_host) *k_host = 0;
+    if (boxes) boxes->done = false;
     PCH_REQUIRE(n >= 0 && n < (int64_t(1) << 31), "n out of range [0, 2^31)");
     PCH_REQUIRE(eps > 0.0, "eps must be > 0 (sklearn: InvalidParameterError)");
     PCH_REQUIRE(min_samples >= 1, "min_samples must be >= 1 (sklearn: InvalidParameterError)");
@@ -1805,7 +1867,12 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
         }
     }
 
-    PCH_HIP_TRY(hipMemsetAsync(w.meta + 6, 0, 4 * sizeof(uint32_t), s));
+    {   // status / cell count / cluster count words and the per-chunk first-cell table, in one 16-byte aligned fill
+        // (meta[4..5] are bounding-box keys nobody reads any more; chunk_cells is written at the first cell of every
+        // chunk by db_cells_k, the zeros make a chunk without a cell an empty range)
+        const size_t bytes = (size_t)(reinterpret_cast<char*>(w.chunk_cells + nchunks + 1) - reinterpret_cast<char*>(w.meta + 4));
+        PCH_HIP_TRY(hipMemsetAsync(w.meta + 4, 0, (bytes + 15) & ~size_t(15), s));
+    }
     const uint64_t* ks;
     // One workgroup per chunk only pays with enough chunks to fill the GPU (measured break-even near
     // 100 chunks of 50 000 rows); PCH_DBSCAN_SORT=chunk / global forces a path (tests compare them)
@@ -1850,11 +1917,8 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
     // the cell count sizes the next grids: fetch it while db_cells_k (sized by n) runs
     uint32_t st_m[2];
     PCH_TRY(peek_enqueue(w.meta + 6, sizeof(st_m), s));
-    // chunk_cells is written at the first cell of every chunk; the memset makes a chunk without a cell
-    // (cannot happen today: NaN/inf chunks keep a cell of their own) an empty range instead of garbage
-    PCH_HIP_TRY(hipMemsetAsync(w.chunk_cells, 0, sizeof(uint32_t) * (size_t)(nchunks + 1), s));
     PCH_LAUNCH("db_cells", db_cells_k, dim3(gn), dim3(DB_THREADS), 0, s, ks, (const uint32_t*)w.head, n,
-               cellbits, nchunks, w.cid, w.cell_start, w.cell_key, w.chunk_cells);
+               cellbits, nchunks, w.cid, w.cell_start, w.cell_key, w.chunk_cells, w.cell_acc);
     PCH_TRY(peek_wait(st_m, sizeof(st_m)));
     if (st_m[0] != 0) {
         set_error("finite coordinates outside the supplied bounding box");
@@ -1878,10 +1942,9 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
                    (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, w.core_s, w.cell_ncore,
                    (unsigned long long*)nullptr);
     }
-    PCH_HIP_TRY(hipMemsetAsync(w.cell_acc, 0, sizeof(uint32_t) * 8 * (size_t)m, s));
     PCH_LAUNCH("db_cellstats", db_cellstats_k, dim3((unsigned)ceil_div(n, (int64_t)DB_WAVES * 64 * DB_CS_ROUNDS)),
                dim3(DB_THREADS), 0, s, (const float4*)w.pts, (const uint32_t*)w.cid, (const uint8_t*)w.core_s, n,
-               w.cell_acc);
+               w.cell_acc, w.flag, ceil_div(n, 32));
     PCH_LAUNCH("db_cellfin", db_cellfin_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
                (const uint32_t*)w.cell_acc, m, w.cell_box, w.cell_min, w.parent, w.comp_min);
     // face neighbours: lane-per-pair first (needs the row table), the wave-wide search for what that left open;
@@ -1909,21 +1972,28 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
     const int64_t nw = ceil_div(n, 32);
     uint32_t* bits = w.flag;
     uint32_t* wrank = w.flag + ((nw + 63) & ~int64_t(63));
-    PCH_HIP_TRY(hipMemsetAsync(bits, 0, sizeof(uint32_t) * (size_t)nw, s));
+    static_assert(DB_CS_ROUNDS * 64 * DB_WAVES / DB_THREADS <= 32, "db_cellstats_k's grid has a thread per bitmap word");
     PCH_LAUNCH("db_mark", db_mark_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
                (const int*)w.root, (const int*)w.comp_min, m, bits);
-    PCH_LAUNCH("db_popc", db_popc_k, dim3((unsigned)ceil_div(nw, DB_THREADS)), dim3(DB_THREADS), 0, s,
-               (const uint32_t*)bits, nw, wrank);
-    PCH_TRY(scan_exclusive_u32(wrank, wrank, nw, w.scan_ws, w.meta + 8, s));
-    PCH_LAUNCH("db_finish", db_finish_k, dim3(1), dim3(64), 0, s, (const uint32_t*)(w.meta + 8), out_nclusters);
+    PCH_TRY(scan_exclusive_popc_u32(bits, wrank, nw, w.scan_ws, w.meta + 8, s));    // word ranks: popcount on load
+    uint32_t* box_acc = (boxes && boxes->acc && boxes->cap > 0) ? boxes->acc : nullptr;
+    const int32_t box_cap = box_acc ? boxes->cap : 0;
+    PCH_LAUNCH("db_prelabel", db_prelabel_k, dim3((unsigned)(box_acc ? ceil_div(8 * (int64_t)box_cap, 256) : 1)),
+               dim3(256), 0, s, (const uint32_t*)(w.meta + 8), out_nclusters, box_acc, 8 * (int64_t)box_cap);
     if (k_host) PCH_TRY(peek_enqueue(out_nclusters, sizeof(int32_t), s));    // read while the labels are written
-    PCH_LAUNCH("db_label", db_label_k, dim3(gn), dim3(DB_THREADS), 0, s, (const float4*)w.pts,
-               (const uint32_t*)w.cid, (const uint8_t*)w.core_s, (const int*)w.root,
-               (const int*)w.comp_min, (const uint32_t*)bits, (const uint32_t*)wrank, n, (const uint32_t*)w.cell_start,
-               w.cell_label, labels, core);
+    {
+        // many chunks: the blocks of one chunk share an XCD (see db_label_k); otherwise blocks in sorted order
+        const int bpc = nchunks >= 16 ? (int)ceil_div(chunk_size, DB_THREADS) : 0;
+        const unsigned gl = bpc > 0 ? (unsigned)(8 * ceil_div(nchunks, 8) * bpc) : gn;
+        PCH_LAUNCH("db_label", db_label_k, dim3(gl), dim3(DB_THREADS), 0, s, (const float4*)w.pts,
+                   (const uint32_t*)w.cid, (const uint8_t*)w.core_s, (const int*)w.root,
+                   (const int*)w.comp_min, (const uint32_t*)bits, (const uint32_t*)wrank, n,
+                   (const uint32_t*)w.cell_start, w.cell_label, labels, core, chunk_size, bpc, nchunks, box_acc, box_cap);
+    }
     PCH_LAUNCH("db_border", db_border_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
                (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, (const uint8_t*)w.core_s,
-               (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, (const int*)w.cell_label, labels);
+               (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, (const int*)w.cell_label, labels, box_acc, box_cap);
+    if (box_acc) boxes->done = true;
     if (k_host) PCH_TRY(peek_wait(k_host, sizeof(int32_t)));
     g_last.ws = ws; g_last.ws_bytes = ws_bytes; g_last.n = n; g_last.m = m; g_last.g = g;
     g_last.has_rowtab = rowtab != nullptr;
@@ -2015,7 +2085,8 @@ extern "C" int pch_dbscan_relabel_i32(const int32_t* map, int32_t nmap, int64_t 
     PCH_LAUNCH("db_border", db_border_k, dim3(gc), dim3(DB_THREADS), 0, s, g, (const float4*)w.pts,
                (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m,
                g_last.has_rowtab ? (const int2*)w.rowtab : (const int2*)nullptr, (const uint8_t*)w.core_s,
-               (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, (const int*)w.cell_label, labels);
+               (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, (const int*)w.cell_label, labels,
+               (uint32_t*)nullptr, 0);
     return PCH_OK;
 }
 

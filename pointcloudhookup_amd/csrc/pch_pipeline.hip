@@ -89,8 +89,11 @@ extern "C" int pch_tower_clusters_f32(const float* raw, int64_t n, double pct, f
     // ---- stage C (the filter's scratch is dead; its outputs are the caller's buffers)
     PCH_REQUIRE(out_labels != nullptr, "out_labels is null");
     int32_t k = 0;                                       // read back while the labels are still being written
+    // the cluster boxes of stage D0 are gathered where the labels are made (no pass of their own): out_stats holds
+    // the encoded table until pch_segment's offsets kernel decodes it in place
+    DbBoxOut box = {reinterpret_cast<uint32_t*>(out_stats), (out_perm && out_offsets && out_stats) ? k_cap : 0, false};
     PCH_TRY(dbscan_run(out_points, nf, eps, min_samples, chunk_size, h.aabb, out_labels, nullptr,
-                       &dev->nclusters, sub, sub_bytes, s, &k));
+                       &dev->nclusters, sub, sub_bytes, s, &k, &box));
     info_host->nclusters = k;
     // ---- stage D0
     if (out_perm && out_offsets) {
@@ -99,8 +102,8 @@ extern "C" int pch_tower_clusters_f32(const float* raw, int64_t n, double pct, f
                       "pch_segment_by_label)", (int)k, (int)k_cap);
             return PCH_ERR_RANGE;
         }
-        PCH_TRY(pch_segment_by_label(out_labels, out_points, nf, k, out_perm, out_offsets, out_stats, sub,
-                                     sub_bytes, stream));
+        PCH_TRY(segment_run(out_labels, out_points, nf, k, out_perm, out_offsets, out_stats, sub, sub_bytes, s,
+                            box.done));
     }
     return PCH_OK;
 }

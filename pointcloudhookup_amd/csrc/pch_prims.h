@@ -9,6 +9,9 @@ namespace pch {
 size_t scan_ws_u32(int64_t n);
 int scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* ws,
                        uint32_t* total, hipStream_t s);
+// the same over popcount(bits[i]) (ranks of the set bits of a bitmap); `out` must NOT alias `bits`
+int scan_exclusive_popc_u32(const uint32_t* bits, uint32_t* out, int64_t n, uint32_t* ws,
+                            uint32_t* total, hipStream_t s);
 
 // ---- stable LSD radix sort of (uint64 key, uint32 value) pairs on key bits [0, nbits).
 // Buffers ping-pong between (k0,v0) and (k1,v1); the sorted result lands in buffer

@@ -11,6 +11,8 @@ constexpr int SC_THREADS = 256;
 constexpr int SC_ITEMS   = 8;
 constexpr int SC_TILE    = SC_THREADS * SC_ITEMS;   // 2048 elements per workgroup
 
+// POPC: the scanned values are the population counts of the input words (row bitmap -> ranks), taken on load
+template <bool POPC>
 __device__ __forceinline__ void sc_load8(const uint32_t* in, int64_t base, int64_t n,
                                          uint32_t (&v)[SC_ITEMS]) {
     if (base + SC_ITEMS <= n) {
@@ -22,15 +24,20 @@ __device__ __forceinline__ void sc_load8(const uint32_t* in, int64_t base, int64
 #pragma unroll
         for (int k = 0; k < SC_ITEMS; ++k) v[k] = (base + k < n) ? in[base + k] : 0u;
     }
+    if (POPC) {
+#pragma unroll
+        for (int k = 0; k < SC_ITEMS; ++k) v[k] = (uint32_t)__popc(v[k]);
+    }
 }
 
+template <bool POPC>
 __global__ __launch_bounds__(SC_THREADS) void scan_reduce_k(const uint32_t* __restrict__ in,
                                                             uint32_t* __restrict__ bsum,
                                                             int64_t n) {
     __shared__ uint32_t wsum[SC_THREADS / 64];
     const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_ITEMS;
     uint32_t v[SC_ITEMS];
-    sc_load8(in, base, n, v);
+    sc_load8<POPC>(in, base, n, v);
     uint32_t s = 0;
 #pragma unroll
     for (int k = 0; k < SC_ITEMS; ++k) s += v[k];
@@ -69,6 +76,7 @@ __global__ __launch_bounds__(1024) void scan_bsums_k(uint32_t* __restrict__ bsum
     if (threadIdx.x == 0 && total) *total = carry_s;
 }
 
+template <bool POPC>
 __global__ __launch_bounds__(SC_THREADS) void scan_apply_k(const uint32_t* in,
                                                            uint32_t* out,
                                                            const uint32_t* __restrict__ bsum,
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(SC_THREADS) void scan_apply_k(const uint32_t* in,
     __shared__ uint32_t wsum[SC_THREADS / 64];
     const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_ITEMS;
     uint32_t v[SC_ITEMS];
-    sc_load8(in, base, n, v);
+    sc_load8<POPC>(in, base, n, v);
     uint32_t s = 0;
 #pragma unroll
     for (int k = 0; k < SC_ITEMS; ++k) { uint32_t t = v[k]; v[k] = s; s += t; }
@@ -104,18 +112,28 @@ size_t scan_ws_u32(int64_t n) {
     return (size_t)nb + 64;
 }
 
-int scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* ws,
-                       uint32_t* total, hipStream_t s) {
+template <bool POPC>
+static int scan_launch(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* ws, uint32_t* total, hipStream_t s) {
     if (n <= 0) {
         if (total) PCH_HIP_TRY(hipMemsetAsync(total, 0, sizeof(uint32_t), s));
         return PCH_OK;
     }
     const int64_t nb = ceil_div(n, SC_TILE);
-    PCH_LAUNCH("scan_reduce", scan_reduce_k, dim3((unsigned)nb), dim3(SC_THREADS), 0, s, in, ws, n);
+    PCH_LAUNCH("scan_reduce", scan_reduce_k<POPC>, dim3((unsigned)nb), dim3(SC_THREADS), 0, s, in, ws, n);
     PCH_LAUNCH("scan_bsums", scan_bsums_k, dim3(1), dim3(1024), 0, s, ws, nb, total);
-    PCH_LAUNCH("scan_apply", scan_apply_k, dim3((unsigned)nb), dim3(SC_THREADS), 0, s, in, out,
+    PCH_LAUNCH("scan_apply", scan_apply_k<POPC>, dim3((unsigned)nb), dim3(SC_THREADS), 0, s, in, out,
                (const uint32_t*)ws, n);
     return PCH_OK;
+}
+
+int scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* ws,
+                       uint32_t* total, hipStream_t s) {
+    return scan_launch<false>(in, out, n, ws, total, s);
+}
+
+int scan_exclusive_popc_u32(const uint32_t* bits, uint32_t* out, int64_t n, uint32_t* ws,
+                            uint32_t* total, hipStream_t s) {
+    return scan_launch<true>(bits, out, n, ws, total, s);
 }
 
 // =====================================================================================

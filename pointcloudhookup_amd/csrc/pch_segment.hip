@@ -17,10 +17,24 @@ __global__ __launch_bounds__(SG_THREADS) void sg_keys_k(const int32_t* __restric
     vals[i] = (uint32_t)i;
 }
 
+// word i of the caller's float [K,8] stats table, in place: the ordered-uint box table stage C left there (DbBoxOut)
+// -> the bit patterns of min xyz, max xyz, 0, 0.  One word per thread (a row-wide version of this crashes the
+// gfx950 instruction selector of ROCm 7.2's clang).
+__device__ __forceinline__ void sg_decode_word(uint32_t* enc, int64_t i) {
+    const int a = (int)(i & 7);
+    const uint32_t u = enc[i];
+    uint32_t v = 0u;
+    if (a < 3) v = u == 0u ? 0x7F800000u : __float_as_uint(f32_unordered(~u));           // +inf: no point
+    else if (a < 6) v = u == 0u ? 0xFF800000u : __float_as_uint(f32_unordered(u));       // -inf
+    enc[i] = v;
+}
+
 // offsets[k] = first sorted position whose key >= k  (k = 0..nclusters); perm = sorted rows
 __global__ __launch_bounds__(SG_THREADS) void sg_offsets_k(const uint64_t* __restrict__ keys, int64_t n,
-                                                           int32_t nclusters, int64_t* __restrict__ offsets) {
+                                                           int32_t nclusters, int64_t* __restrict__ offsets,
+                                                           uint32_t* enc_stats) {
     const int64_t k = (int64_t)blockIdx.x * SG_THREADS + threadIdx.x;
+    if (enc_stats && k < 8 * (int64_t)nclusters) sg_decode_word(enc_stats, k);
     if (k > nclusters) return;
     int64_t lo = 0, hi = n;
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys[mid] < (uint64_t)k) lo = mid + 1; else hi = mid; }
@@ -196,9 +210,11 @@ __global__ __launch_bounds__(SG_THREADS) void sl_scatter_k(const int32_t* __rest
 
 // offsets[k] = start of bin k = scanned count of (bin k, tile 0); offsets[K] = start of the noise rows
 __global__ __launch_bounds__(SG_THREADS) void sl_offsets_k(const uint32_t* __restrict__ offs, int64_t nb,
-                                                           int32_t nclusters, int64_t* __restrict__ offsets) {
+                                                           int32_t nclusters, int64_t* __restrict__ offsets,
+                                                           uint32_t* enc_stats) {
     const int k = blockIdx.x * SG_THREADS + threadIdx.x;
     if (k <= nclusters) offsets[k] = (int64_t)offs[(int64_t)k * nb];
+    if (enc_stats && k < 8 * nclusters) sg_decode_word(enc_stats, k);
 }
 
 __global__ __launch_bounds__(SG_THREADS) void sg_stats_out_k(const uint32_t* __restrict__ acc, int32_t nclusters,
@@ -254,7 +270,13 @@ extern "C" int pch_segment_by_label(const int32_t* labels, const float* xyz, int
                                     int32_t nclusters, int32_t* out_perm, int64_t* out_offsets,
                                     float* out_stats, void* ws, size_t ws_bytes, void* stream) {
     PCH_DEVICE_GUARD(labels ? (const void*)labels : (const void*)out_offsets);
-    hipStream_t s = (hipStream_t)stream;
+    return segment_run(labels, xyz, n, nclusters, out_perm, out_offsets, out_stats, ws, ws_bytes, (hipStream_t)stream,
+                       false);
+}
+
+int pch::segment_run(const int32_t* labels, const float* xyz, int64_t n, int32_t nclusters, int32_t* out_perm,
+                     int64_t* out_offsets, float* out_stats, void* ws, size_t ws_bytes, hipStream_t s,
+                     bool stats_encoded) {
     PCH_REQUIRE(n >= 0 && n < (int64_t(1) << 31) && nclusters >= 0, "bad size");
     PCH_REQUIRE(out_offsets != nullptr, "out_offsets is null");
     if (n == 0) {
@@ -276,8 +298,10 @@ extern "C" int pch_segment_by_label(const int32_t* labels, const float* xyz, int
         PCH_TRY(scan_exclusive_u32(w.table, w.table, table, w.table_scan, nullptr, s));
         PCH_LAUNCH("seg_scatter", sl_scatter_k, dim3((unsigned)nb), dim3(SG_THREADS), 0, s, labels, n, nclusters,
                    (const uint32_t*)w.table, nb, out_perm);
-        PCH_LAUNCH("seg_offsets", sl_offsets_k, dim3((unsigned)ceil_div((int64_t)nclusters + 1, SG_THREADS)),
-                   dim3(SG_THREADS), 0, s, (const uint32_t*)w.table, nb, nclusters, out_offsets);
+        PCH_LAUNCH("seg_offsets", sl_offsets_k,
+                   dim3((unsigned)ceil_div(stats_encoded ? 8 * (int64_t)nclusters + 1 : (int64_t)nclusters + 1, SG_THREADS)),
+                   dim3(SG_THREADS), 0, s, (const uint32_t*)w.table, nb, nclusters, out_offsets,
+                   stats_encoded ? reinterpret_cast<uint32_t*>(out_stats) : (uint32_t*)nullptr);
     } else {
         PCH_LAUNCH("seg_keys", sg_keys_k, dim3(gn), dim3(SG_THREADS), 0, s, labels, n, nclusters, w.k0, w.v0);
         const int nbits = bits_for((uint64_t)nclusters + 1);
@@ -286,10 +310,12 @@ extern "C" int pch_segment_by_label(const int32_t* labels, const float* xyz, int
         const uint64_t* ks = in1 ? w.k1 : w.k0;
         const uint32_t* vs = in1 ? w.v1 : w.v0;
         PCH_LAUNCH("seg_perm", sg_perm_k, dim3(gn), dim3(SG_THREADS), 0, s, vs, n, out_perm);
-        PCH_LAUNCH("seg_offsets", sg_offsets_k, dim3((unsigned)ceil_div((int64_t)nclusters + 1, SG_THREADS)),
-                   dim3(SG_THREADS), 0, s, ks, n, nclusters, out_offsets);
+        PCH_LAUNCH("seg_offsets", sg_offsets_k,
+                   dim3((unsigned)ceil_div(stats_encoded ? 8 * (int64_t)nclusters + 1 : (int64_t)nclusters + 1, SG_THREADS)),
+                   dim3(SG_THREADS), 0, s, ks, n, nclusters, out_offsets,
+                   stats_encoded ? reinterpret_cast<uint32_t*>(out_stats) : (uint32_t*)nullptr);
     }
-    if (out_stats && nclusters > 0) {
+    if (out_stats && nclusters > 0 && !stats_encoded) {
         PCH_LAUNCH("seg_stats_init", sg_stats_init_k, dim3((unsigned)ceil_div(6 * (int64_t)nclusters, SG_THREADS)),
                    dim3(SG_THREADS), 0, s, w.acc, nclusters);
         PCH_LAUNCH("seg_stats", sg_stats_k, dim3((unsigned)ceil_div(n, 1024 * (SG_THREADS / 64))), dim3(SG_THREADS),

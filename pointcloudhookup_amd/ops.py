@@ -446,7 +446,7 @@ def tower_clusters(raw, eps=8.0, min_samples=80, chunk_size=50000, pct=25.0, off
         for nf_cap in caps:
             labels = torch.empty((nf_cap,), dtype=torch.int32, device=dev)
             perm = torch.empty((nf_cap,), dtype=torch.int32, device=dev) if segment else None
-            offsets = torch.zeros((k_cap + 1,), dtype=torch.int64, device=dev) if segment else None
+            offsets = torch.empty((k_cap + 1,), dtype=torch.int64, device=dev) if segment else None   # [0..k] are written
             stats = torch.empty((k_cap, 8), dtype=torch.float32, device=dev) if segment else None
             ws = _workspace(L.pch_tower_clusters_ws_bytes(n, nf_cap, k_cap), dev)
             rc = L.pch_tower_clusters_f32(_ptr(raw), n, float(pct), float(offset), float(fallback_offset),
