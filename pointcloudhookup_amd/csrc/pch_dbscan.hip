@@ -1669,12 +1669,15 @@ struct DbWs {
     uint32_t* comp;          // [n][3] compressed cell coordinates (fallback for grids beyond the 64-bit key)
     uint32_t* flag2;         // [n + 8] head flags kept beside their scan
     unsigned long long* core_stats;   // [4] tallies of db_core_k<true> (pch_dbscan_set_pair_counting)
+    uint32_t *scan1_a, *scan1_b;      // zeroed words of the single-pass scans (cell ids; cluster ranks)
 };
 
 static void db_plan(Arena& a, int64_t n, DbWs& w) {
     const int64_t nn = n > 0 ? n : 1;
     w.meta = a.take<uint32_t>(64);                       // exactly one 256-byte arena block ...
-    w.chunk_cells = a.take<uint32_t>(nn + 8);            // ... directly followed by this: ONE memset clears both
+    w.scan1_a = a.take<uint32_t>(scan1_ws_u32(nn));      // ... directly followed by the zero-initialised words of the
+    w.scan1_b = a.take<uint32_t>(scan1_ws_u32(nn / 32 + 1));   // two single-pass scans and by the per-chunk table:
+    w.chunk_cells = a.take<uint32_t>(nn + 8);            // ONE fill clears them all (db_plan keeps them adjacent)
     w.core_stats = a.take<unsigned long long>(4);
     w.chunk_bad = a.take<uint32_t>(nn + 8);              // one word per chunk (chunk_size >= 1)
     w.k0 = a.take<uint64_t>(nn);
@@ -1961,7 +1964,8 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
         const uint32_t* vs = in1 ? w.v1 : w.v0;
         PCH_LAUNCH("db_gather", db_gather_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, ks, vs, n, w.pts, w.head);
     }
-    PCH_TRY(scan_exclusive_u32(w.head, w.head, n, w.scan_ws, w.meta + 7, s));
+    if (scan1_pays(n)) PCH_TRY(scan1_exclusive_u32(w.head, w.head, n, w.scan1_a, w.meta + 7, s));
+    else PCH_TRY(scan_exclusive_u32(w.head, w.head, n, w.scan_ws, w.meta + 7, s));
     // the cell count sizes the next grids: fetch it while db_cells_k (sized by n) runs
     uint32_t st_m[2];
     PCH_TRY(peek_enqueue(w.meta + 6, sizeof(st_m), s));
@@ -1971,6 +1975,10 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
     if (st_m[0] != 0) {
         set_error("finite coordinates outside the supplied bounding box");
         return PCH_ERR_ARG;
+    }
+    if (st_m[1] == 0xFFFFFFFFu) {                       // the single-pass scan's bounded wait gave up (pch_prims.h)
+        set_error("stage C: a device-side look-back wait ran out of its budget; outputs are undefined");
+        return PCH_ERR_TIMEOUT;
     }
     const int m = (int)st_m[1];
     const unsigned gc = (unsigned)ceil_div(m, DB_WAVES);
@@ -2023,7 +2031,9 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
     static_assert(DB_CS_ROUNDS * 64 * DB_WAVES / DB_THREADS <= 32, "db_cellstats_k's grid has a thread per bitmap word");
     PCH_LAUNCH("db_mark", db_mark_k, dim3((unsigned)ceil_div(m, DB_THREADS)), dim3(DB_THREADS), 0, s,
                (const int*)w.root, (const int*)w.comp_min, m, bits);
-    PCH_TRY(scan_exclusive_popc_u32(bits, wrank, nw, w.scan_ws, w.meta + 8, s));    // word ranks: popcount on load
+    // word ranks: popcount on load
+    if (scan1_pays(nw)) PCH_TRY(scan1_exclusive_popc_u32(bits, wrank, nw, w.scan1_b, w.meta + 8, s));
+    else PCH_TRY(scan_exclusive_popc_u32(bits, wrank, nw, w.scan_ws, w.meta + 8, s));
     static const bool no_fold = getenv("PCH_DB_NO_BOXFOLD") != nullptr;     // tuning toggle
     uint32_t* box_acc = (boxes && boxes->acc && boxes->cap > 0 && !no_fold) ? boxes->acc : nullptr;
     const int32_t box_cap = box_acc ? boxes->cap : 0;
@@ -2044,7 +2054,13 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
                (const uint32_t*)w.cell_start, (const uint64_t*)w.cell_key, m, rowtab, (const uint8_t*)w.core_s,
                (const uint32_t*)w.cell_ncore, (const float*)w.cell_box, (const int*)w.cell_label, labels, box_acc, box_cap);
     if (box_acc) boxes->done = true;
-    if (k_host) PCH_TRY(peek_wait(k_host, sizeof(int32_t)));
+    if (k_host) {
+        PCH_TRY(peek_wait(k_host, sizeof(int32_t)));
+        if (*k_host < 0) {                              // the rank scan's bounded wait gave up: the count reads -1
+            set_error("stage C: a device-side look-back wait ran out of its budget; outputs are undefined");
+            return PCH_ERR_TIMEOUT;
+        }
+    }
     g_last.ws = ws; g_last.ws_bytes = ws_bytes; g_last.n = n; g_last.m = m; g_last.g = g;
     g_last.has_rowtab = rowtab != nullptr;
     return PCH_OK;

@@ -125,8 +125,13 @@ __device__ __forceinline__ uint32_t sl_bin(int32_t l, int32_t nclusters) {
 
 __global__ __launch_bounds__(SG_THREADS) void sl_hist_k(const int32_t* __restrict__ labels, int64_t n,
                                                         int32_t nclusters, uint32_t* __restrict__ hist,
-                                                        int64_t nb) {
+                                                        int64_t nb, uint32_t* __restrict__ zero_ws,
+                                                        int64_t zero_words) {
     __shared__ uint32_t h[256];
+    {   // the single-pass scan of the count table that follows needs its status words zeroed (pch_prims.h)
+        const int64_t g = (int64_t)blockIdx.x * SG_THREADS + threadIdx.x;
+        if (g < zero_words) zero_ws[g] = 0u;
+    }
     h[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * SL_TILE;
@@ -242,7 +247,7 @@ static void sg_plan(Arena& a, int64_t n, int32_t nclusters, SgWs& w) {
     if (nclusters < 256) {                                 // labels + noise fit one 8-bit digit
         const int64_t table = ((int64_t)nclusters + 1) * ceil_div(nn, SL_TILE);
         w.table = a.take<uint32_t>(table);
-        w.table_scan = a.take<uint32_t>(scan_ws_u32(table));
+        w.table_scan = a.take<uint32_t>(scan1_pays(table) ? scan1_ws_u32(table) : scan_ws_u32(table));
         w.k0 = w.k1 = nullptr; w.v0 = w.v1 = w.radix_ws = nullptr;
     } else {
         w.table = w.table_scan = nullptr;
@@ -293,9 +298,13 @@ int pch::segment_run(const int32_t* labels, const float* xyz, int64_t n, int32_t
     if (nclusters < 256) {
         const int64_t nb = ceil_div(n, SL_TILE);
         const int64_t table = ((int64_t)nclusters + 1) * nb;
+        const bool one = scan1_pays(table);
+        const int64_t zero_words = one ? (int64_t)scan1_ws_u32(table) : 0;
+        PCH_REQUIRE(zero_words <= nb * SG_THREADS, "count table too large for the fused zeroing");   // (K+1)/1024 < 256
         PCH_LAUNCH("seg_hist", sl_hist_k, dim3((unsigned)nb), dim3(SG_THREADS), 0, s, labels, n, nclusters,
-                   w.table, nb);
-        PCH_TRY(scan_exclusive_u32(w.table, w.table, table, w.table_scan, nullptr, s));
+                   w.table, nb, w.table_scan, zero_words);
+        if (one) PCH_TRY(scan1_exclusive_u32(w.table, w.table, table, w.table_scan, nullptr, s));
+        else PCH_TRY(scan_exclusive_u32(w.table, w.table, table, w.table_scan, nullptr, s));
         PCH_LAUNCH("seg_scatter", sl_scatter_k, dim3((unsigned)nb), dim3(SG_THREADS), 0, s, labels, n, nclusters,
                    (const uint32_t*)w.table, nb, out_perm);
         PCH_LAUNCH("seg_offsets", sl_offsets_k,

@@ -320,7 +320,7 @@ def dbscan(xyz, eps=8.0, min_samples=80, chunk_size=50000, aabb=None, want_core=
         _lib.check(L.pch_dbscan_f32(_ptr(xyz), n, float(eps), int(min_samples), int(chunk_size),
                                     None if box is None else C.cast(box, C.c_void_p), _ptr(labels),
                                     _ptr(core), _ptr(ncl), _ptr(ws), ws.numel(), _stream()))
-        k = int(ncl.item())
+        k = _lib.check_count(ncl.item(), "dbscan")
     return labels, core, k
 
 
@@ -348,7 +348,7 @@ class DbscanFit:
                                         None if box is None else C.cast(box, C.c_void_p), _ptr(self.labels),
                                         _ptr(self.core), _ptr(ncl), _ptr(self.workspace), self.workspace.numel(),
                                         _stream()))
-            self.nclusters = int(ncl.item())
+            self.nclusters = _lib.check_count(ncl.item(), "dbscan")
 
     def first_core_rows(self):
         """Smallest core row of every cluster (int32 [nclusters], ascending with the cluster id)."""
