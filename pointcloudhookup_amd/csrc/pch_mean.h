@@ -6,7 +6,9 @@ namespace pch {
 
 struct MsHdr;
 struct MsRec;
+struct MsPred;
 struct MsWs {
+    MsPred*    pred;             // [3][nb2] estimated running sum in front of every level-2 row (candidate windows)
     int*       stats;            // [3][4]: level-2 batches, -, exactly added blocks, descents
     MsRec*     rec;              // [3][nb] level-1 records (three 128-byte lines per column and block)
     MsHdr*     hdr2;

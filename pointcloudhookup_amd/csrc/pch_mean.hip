@@ -33,7 +33,10 @@ constexpr uint32_t MS_NONFINITE = 1u, MS_ALLZERO = 2u;
 constexpr int MS_FIX_FROM = 11;     // sparse-tie fix-up for candidates >= this ...
 constexpr int MS_FIX_MAX  = 8;      // ... holding at most this many tie elements
 
-struct MsHdr { int emax; uint32_t tie; uint32_t flags; uint32_t pad; };
+// mask: candidates j whose S / fix entries were computed (bit j); a candidate outside the mask is "unknown" to the walk
+struct MsHdr { int emax; uint32_t tie; uint32_t flags; uint32_t mask; };
+constexpr uint32_t MS_ALLCAND = (1u << MS_CAND) - 1u;
+constexpr int MS_WIN = 4;           // predicted window: candidates jp-1 .. jp+2 (+ candidate 0, always computed)
 
 // level-1 record of one (column, block): three 128-byte lines, assembled in LDS and written by one
 // store instruction (whole lines: no read-modify-write in HBM), read by the lane that owns the
@@ -95,9 +98,92 @@ __device__ __forceinline__ uint32_t ms_tie_bit(float x) {
     return ((float)Y == y) ? (uint32_t)(Y & -Y) : 0u;
 }
 
+// ---- which candidates will the walk ask for? ------------------------------------------------------------------
+// The walk reads a block's table at ONE candidate: the binade of the float32 running sum when it gets there.  That
+// binade follows from the prefix of the column, which a block cannot know - but it can be ESTIMATED cheaply: one
+// sampled row per block gives the sum of every 65 536-point row (ms_sample_k), a prefix over the rows (ms_prefix_k)
+// the running sum in front of every row, and the float32 sum stops growing roughly 25 binades above the typical
+// element (increments round to zero).  ms_summary_k then computes candidate 0 and a window of MS_WIN candidates around
+// the estimate instead of all 24 (2.4x fewer vector instructions: the kernel is bound by them).  A wrong estimate
+// costs time, never exactness: a candidate that was not computed is "unknown" to the walk, which then adds the
+// block element by element (ms_block_exact).  Blocks with both signs, non-finite values or a prefix dominated by
+// cancellation keep all 24 candidates.
+struct MsPred { double pre, rowsum, meanabs; };          // per (column, level-2 row)
+
+__global__ __launch_bounds__(64) void ms_sample_k(const float* __restrict__ xyz, int64_t n, int64_t nb, int64_t nb2,
+                                                  MsPred* __restrict__ pred) {
+    const int64_t row = blockIdx.x;
+    const int l = lane_id();
+    const int64_t blk = row * 64 + l;
+    double v[3] = {0.0, 0.0, 0.0}, av[3] = {0.0, 0.0, 0.0};
+    int have = 0;
+    if (blk < nb) {
+        const int64_t p0 = blk * MSB;
+        const int64_t cnt = (n - p0) < MSB ? (n - p0) : MSB;
+        const int64_t p = p0 + (int64_t)(((uint32_t)blk * 2654435761u) >> 22) % cnt;   // one pseudo-random row of the block
+        struct Row3 { float x, y, z; };
+        const Row3 q = reinterpret_cast<const Row3*>(xyz)[p];
+        v[0] = q.x; v[1] = q.y; v[2] = q.z;
+        have = 1;
+    }
+    const int64_t first = row * 64 * MSB;
+    const double cnt_row = (double)((n - first) < (int64_t)64 * MSB ? (n - first) : (int64_t)64 * MSB);
+    const double ns = (double)__popcll(__ballot(have != 0));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const bool fin = fabs(v[c]) < 1.0e300;             // NaN / inf samples: no estimate from them
+        av[c] = fin ? fabs(v[c]) : 0.0;
+        v[c] = fin ? v[c] : 0.0;
+        double sv = v[c], sa = av[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sv += __shfl_xor(sv, o, 64); sa += __shfl_xor(sa, o, 64); }
+        if (l == 0) {
+            MsPred o;
+            o.pre = 0.0;
+            o.rowsum = ns > 0.0 ? sv / ns * cnt_row : 0.0;
+            o.meanabs = ns > 0.0 ? sa / ns : 0.0;
+            pred[(int64_t)c * nb2 + row] = o;
+        }
+    }
+}
+
+// exclusive prefix of the row sums per column (one 1024-thread workgroup per column: a block scan per 1024 rows),
+// starting from the incoming running sum
+__global__ __launch_bounds__(1024) void ms_prefix_k(MsPred* __restrict__ pred, int64_t nb2,
+                                                    const float* __restrict__ sum_in) {
+    __shared__ double wsum[16];
+    __shared__ double carry_sh;
+    const int c = blockIdx.x;
+    const int l = lane_id(), w = wave_id();
+    if (threadIdx.x == 0) carry_sh = sum_in ? (double)sum_in[c] : 0.0;
+    __syncthreads();
+    for (int64_t r0 = 0; r0 < nb2; r0 += 1024) {
+        const int64_t r = r0 + threadIdx.x;
+        const double v = r < nb2 ? pred[(int64_t)c * nb2 + r].rowsum : 0.0;
+        double incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(incl, o, 64); if (l >= o) incl += t; }
+        if (l == 63) wsum[w] = incl;
+        __syncthreads();
+        double woff = 0.0, total = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const double t = wsum[k]; woff += k < w ? t : 0.0; total += t; }
+        const double carry = carry_sh;
+        if (r < nb2) pred[(int64_t)c * nb2 + r].pre = carry + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_sh = carry + total;
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int ms_exp2_floor(double x) {        // floor(log2 |x|) of a finite double, -1023 for 0
+    return (int)((((unsigned long long)__double_as_longlong(x)) >> 52) & 0x7FFull) - 1023;
+}
+
 __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __restrict__ xyz, int64_t n,
                                                              int64_t nb, MsRec* __restrict__ recs,
-                                                             float* __restrict__ zcol) {
+                                                             float* __restrict__ zcol,
+                                                             const MsPred* __restrict__ pred, int64_t nb2) {
     __shared__ __attribute__((aligned(16))) float lds[MS_WAVES][MSB * 3];
     __shared__ MsRec stage[MS_WAVES];                    // a record is assembled here, stored as whole lines
     const int64_t blk = (int64_t)blockIdx.x * MS_WAVES + wave_id();
@@ -153,7 +239,57 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         int S[MS_CAND];
 #pragma unroll
         for (int j = 0; j < MS_CAND; ++j) S[j] = 0;
-        if (live) {
+        // ---- candidate window (wave-uniform): see the comment above ms_sample_k
+        uint32_t cmask = MS_ALLCAND;
+        int j0 = 1;                                            // first candidate of the window (>= 1)
+        if (live && pred) {
+            bool neg = false, pos = false;
+#pragma unroll
+            for (int i = 0; i < MS_PER; ++i) { neg |= a[i] < 0.0f; pos |= a[i] > 0.0f; }
+            const bool mixed = __ballot(neg) != 0 && __ballot(pos) != 0;
+            const MsPred pr = pred[(int64_t)c * nb2 + (blk >> 6)];
+            const double start = pr.pre + pr.rowsum * ((double)(blk & 63) * (1.0 / 64.0));
+            const double mass = fabs(pr.pre) + fabs(pr.rowsum);
+            // a prefix that is mostly cancellation (|sum| far below the mass that went into it) is not predictable
+            const bool cancel = !(fabs(start) * 8.0 >= pr.meanabs * (double)(blk * MSB)) && blk > 0;
+            if (!mixed && !cancel && mass > 0.0 && pr.meanabs > 0.0) {
+                int E = ms_exp2_floor(start);
+                const int Estag = ms_exp2_floor(pr.meanabs) + 25;       // increments round to zero up there
+                E = E < Estag ? E : Estag;
+                int jp = E - emax - 1;                                  // candidate of binade E for THIS block
+                jp = jp < 2 ? 2 : jp;                                   // window = jp-1 .. jp+2, inside 1 .. 23
+                jp = jp > MS_CAND - 3 ? MS_CAND - 3 : jp;
+                j0 = jp - 1;
+                cmask = 1u | (((1u << MS_WIN) - 1u) << j0);
+            }
+        }
+        if (live && cmask != MS_ALLCAND) {
+            float magic[MS_WIN];
+            uint32_t acc[MS_WIN], acc0 = 0;
+#pragma unroll
+            for (int k = 0; k < MS_WIN; ++k) {
+                magic[k] = ldexpf(1.5f, 23 + j0 + k);                   // 1.5 * 2^(23+j), exact
+                acc[k] = 0u - (uint32_t)MS_PER * __float_as_uint(magic[k]);
+            }
+            float absum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < MS_PER; ++i) {
+                const float x = ldexpf(a[i], 22 - emax);       // a / ulp(2^(emax+1)), |x| < 2^23, exact
+                absum += fabsf(x);
+                tie |= ms_tie_bit(x);
+                acc0 += (uint32_t)(int)rintf(x);
+#pragma unroll
+                for (int k = 0; k < MS_WIN; ++k) acc[k] += __float_as_uint(x + magic[k]);
+            }
+            S[0] = (int)acc0;
+#pragma unroll
+            for (int j = 1; j < MS_CAND; ++j) {
+#pragma unroll
+                for (int k = 0; k < MS_WIN; ++k) S[j] = (j == j0 + k) ? (int)acc[k] : S[j];
+            }
+            A0 = (int)ceilf(absum * 1.00001f) + 1;
+            tie &= cmask;                                      // ties of candidates that were not computed do not matter
+        } else if (live) {
             uint32_t acc[MS_CAND];                             // start at minus the 16 constants that get added
             acc[0] = 0;
 #pragma unroll
@@ -268,7 +404,7 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
             rec->h.emax = emax;
             rec->h.tie = tie;
             rec->h.flags = (nonfinite ? MS_NONFINITE : 0u) | (mx == 0 ? MS_ALLZERO : 0u);
-            rec->h.pad = 0;
+            rec->h.mask = cmask;
         }
         __builtin_amdgcn_wave_barrier();
         if (l < 24)                                            // 24 x 16 bytes: three full lines
@@ -412,7 +548,7 @@ __global__ __launch_bounds__(256) void ms_level2_k(const MsRec* __restrict__ rec
     // with coalesced 16-byte loads; lane l of every wave then reads the record of child l, and
     // each of the four waves composes six of the 24 candidates
     __shared__ uint32_t sh[64 * MS_L2_PITCH];
-    __shared__ uint32_t tie_sh;
+    __shared__ uint32_t tie_sh, miss_sh;
     const int64_t w = blockIdx.x;
     const int c = (int)(w / nb2);
     const int64_t g = w % nb2;
@@ -437,19 +573,19 @@ __global__ __launch_bounds__(256) void ms_level2_k(const MsRec* __restrict__ rec
                 d[0] = q[it].x; d[1] = q[it].y; d[2] = q[it].z; d[3] = q[it].w;
             }
         }
-        if (threadIdx.x == 0) tie_sh = 0;
+        if (threadIdx.x == 0) { tie_sh = 0; miss_sh = 0; }
         __syncthreads();
     }
     const uint32_t* rec = sh + l * MS_L2_PITCH;           // words: hdr 0..3, A0 4..5, S[j] 6+2j, fix[j] 54+j
     auto rec64 = [&](int word) { return (long long)(((unsigned long long)rec[word + 1] << 32) | rec[word]); };
     MsHdr h;
-    h.emax = -200; h.tie = 0; h.flags = MS_ALLZERO; h.pad = 0;
-    if (valid) { h.emax = (int)rec[0]; h.tie = rec[1]; h.flags = rec[2]; }
+    h.emax = -200; h.tie = 0; h.flags = MS_ALLZERO; h.mask = MS_ALLCAND;
+    if (valid) { h.emax = (int)rec[0]; h.tie = rec[1]; h.flags = rec[2]; h.mask = rec[3]; }
     const bool zero = (h.flags & MS_ALLZERO) != 0;
     const int emax2 = wave_reduce_max(zero ? -200 : h.emax);
     const uint32_t nonfinite = __ballot((h.flags & MS_NONFINITE) != 0) ? MS_NONFINITE : 0u;
     const bool allzero = __ballot(!zero) == 0;
-    uint32_t tie2 = 0;
+    uint32_t tie2 = 0, miss2 = 0;                          // miss2: candidates some child did not compute
     const int shift = emax2 - h.emax;                      // >= 0 for non-zero children
     const bool live = valid && !zero && !(h.flags & MS_NONFINITE);
     const long long A0 = live ? rec64(4) : 0;
@@ -457,6 +593,7 @@ __global__ __launch_bounds__(256) void ms_level2_k(const MsRec* __restrict__ rec
         const int j = j2 + shift;
         long long n0 = 0, n1 = 0, A = 0;
         bool tie = false;
+        if (__ballot(live && j < MS_CAND && !((h.mask >> j) & 1u))) miss2 |= 1u << j2;
         if (live && j < MS_CAND) {
             const long long S = rec64(6 + 2 * j);
             const uint32_t f = rec[6 + 2 * MS_CAND + j];
@@ -482,13 +619,14 @@ __global__ __launch_bounds__(256) void ms_level2_k(const MsRec* __restrict__ rec
         }
     }
     if (l == 0 && tie2) atomicOr(&tie_sh, tie2);
+    if (l == 0 && miss2) atomicOr(&miss_sh, miss2);
     __syncthreads();
     if (threadIdx.x == 0) {
         MsHdr o;
         o.emax = allzero ? 0 : emax2;
         o.tie = tie_sh;
         o.flags = nonfinite | (allzero ? MS_ALLZERO : 0u);
-        o.pad = 0;
+        o.mask = MS_ALLCAND & ~miss_sh;
         hdr2[(int64_t)c * nb2 + g] = o;
     }
 }
@@ -505,6 +643,7 @@ __device__ __forceinline__ int ms_classify(const MsHdr& h, bool valid, bool s_in
     if (s_inf) return (h.flags & MS_NONFINITE) ? 2 : 0;
     if (!s_norm || (h.flags & MS_NONFINITE) || j < 0) return 2;
     if (j >= MS_CAND) return 0;
+    if (!((h.mask >> j) & 1u)) return 2;                 // candidate not computed (prediction window missed it)
     return ((h.tie >> j) & 1u) ? 2 : 1;
 }
 
@@ -548,7 +687,8 @@ __device__ __forceinline__ int ms_certify(int cls, const MsEntry& e, bool valid,
 // Adds the level-1 blocks [first, first+count), count <= 64, to the running sum `sb` (bits).
 __device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ xyz, int64_t n, int c,
                                                      const MsTables& T, int64_t first, int count,
-                                                     uint32_t sb, float* stage, int& n_exact, int& serial_len) {
+                                                     uint32_t sb, float* stage, int& n_exact, int& serial_len,
+                                                     int& n_miss) {
     const int l = lane_id();
     int done = 0;                                       // children already added
     while (done < count) {
@@ -561,7 +701,7 @@ __device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ x
         const int64_t bb = first + l;
         const bool valid = l >= done && l < count;
         MsHdr h;
-        h.emax = 0; h.tie = 0; h.flags = MS_ALLZERO; h.pad = 0;
+        h.emax = 0; h.tie = 0; h.flags = MS_ALLZERO; h.mask = MS_ALLCAND;
         const MsRec* rec = T.rec + (int64_t)c * T.nb + (valid ? bb : first);
         if (valid) h = rec->h;
         int j;
@@ -581,6 +721,11 @@ __device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ x
             if (f < 0) { done = count; break; }
             // child f cannot be certified from the table at this binade: add it exactly
             ++n_exact;
+            {
+                const uint32_t mk = (uint32_t)__builtin_amdgcn_readlane((int)h.mask, f);
+                const int jf = __builtin_amdgcn_readlane(j, f);
+                if (jf >= 0 && jf < MS_CAND && !((mk >> jf) & 1u)) ++n_miss;
+            }
             const uint32_t nsb = ms_block_exact(xyz, n, c, first + f, sb, stage, serial_len);
             const bool same = ((nsb ^ sb) & 0xFF800000u) == 0 && s_norm;   // same sign and binade
             sb = nsb;
@@ -605,7 +750,7 @@ __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, i
     const int l = lane_id();
     uint32_t sb = sum_in ? __float_as_uint(sum_in[c]) : 0u;      // bits of the running sum (+0.0 at the start)
     int64_t b = 0;                                     // next level-2 row
-    int n_exact = 0, n_batches = 0, n_desc = 0;
+    int n_exact = 0, n_batches = 0, n_desc = 0, n_miss = 0;
     int serial_len = MS_SEG;
     while (b < T.nb2) {
         ++n_batches;
@@ -618,7 +763,7 @@ __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, i
         const int64_t bb = b + l;
         const bool valid = bb < T.nb2;
         MsHdr h;
-        h.emax = 0; h.tie = 0; h.flags = MS_ALLZERO; h.pad = 0;
+        h.emax = 0; h.tie = 0; h.flags = MS_ALLZERO; h.mask = MS_ALLCAND;
         if (valid) h = T.hdr2[(int64_t)c * T.nb2 + bb];
         int j;
         const int cls = ms_classify(h, valid, s_inf, s_norm, E, j);
@@ -638,7 +783,7 @@ __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, i
             ++n_desc;
             const int64_t first = (b + f) * 64;
             const int count = (int)((T.nb - first) < 64 ? (T.nb - first) : 64);
-            const uint32_t nsb = ms_walk_children(xyz, n, c, T, first, count, sb, stage, n_exact, serial_len);
+            const uint32_t nsb = ms_walk_children(xyz, n, c, T, first, count, sb, stage, n_exact, serial_len, n_miss);
             const bool same = ((nsb ^ sb) & 0xFF800000u) == 0 && s_norm;
             sb = nsb;
             start = f + 1;
@@ -651,7 +796,7 @@ __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, i
         // n == 0 -> 0/0 = NaN like numpy
         out[c] = divide ? __uint_as_float(sb) / (float)divide_n : __uint_as_float(sb);
         if (stats) {
-            stats[4 * c + 0] = n_batches; stats[4 * c + 1] = 0;
+            stats[4 * c + 0] = n_batches; stats[4 * c + 1] = n_miss;     // n_miss: exact blocks the window caused
             stats[4 * c + 2] = n_exact; stats[4 * c + 3] = n_desc;
         }
     }
@@ -690,6 +835,7 @@ void ms_plan(Arena& a, int64_t n, MsWs& w) {
     const int64_t nb = ceil_div(n > 0 ? n : 1, MSB);
     const int64_t nb2 = ceil_div(nb, 64);
     w.stats = a.take<int>(16);
+    w.pred = a.take<MsPred>(3 * nb2);
     w.rec = a.take<MsRec>(3 * nb);
     w.hdr2 = a.take<MsHdr>(3 * nb2);
     w.rows2 = a.take<long long>(3 * nb2 * MS_ROW2);
@@ -700,8 +846,17 @@ int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zco
     const int64_t nb = n > 0 ? ceil_div(n, MSB) : 0;
     const int64_t nb2 = ceil_div(nb, 64);
     if (n > 0 && phase != MS_PHASE_WALK) {
+        // candidate prediction (see ms_sample_k): only when the running sum the rows continue is known now -
+        // the whole sum (phase both), not for tables built ahead of their walk - and the array spans several rows
+        static const bool no_predict = getenv("PCH_MEAN_NO_PREDICT") != nullptr;      // tuning toggle
+        const MsPred* pred = nullptr;
+        if (!no_predict && phase == MS_PHASE_BOTH && nb2 >= 2) {
+            PCH_LAUNCH("mean_sample", ms_sample_k, dim3((unsigned)nb2), dim3(64), 0, s, xyz, n, nb, nb2, w.pred);
+            PCH_LAUNCH("mean_prefix", ms_prefix_k, dim3(3), dim3(1024), 0, s, w.pred, nb2, sum_in);
+            pred = w.pred;
+        }
         PCH_LAUNCH("mean_summary", ms_summary_k, dim3((unsigned)ceil_div(nb, MS_WAVES)), dim3(64 * MS_WAVES),
-                   0, s, xyz, n, nb, w.rec, zcol);
+                   0, s, xyz, n, nb, w.rec, zcol, pred, nb2);
         if (ev_zcol) PCH_HIP_TRY(hipEventRecord(ev_zcol, s));
         PCH_LAUNCH("mean_level2", ms_level2_k, dim3((unsigned)(3 * nb2)), dim3(256), 0, s,
                    (const MsRec*)w.rec, nb, nb2, w.hdr2, w.rows2);

@@ -11,8 +11,8 @@ from pointcloudhookup_amd import _lib, ops, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
 L = _lib.lib()
-for offset in (True, False):
-    x = synth.corridor_torch(n, seed=synth.SEED0 + 2, kind="corridor", offset=offset, device="cuda", dtype=torch.float32)
+for kind, offset in (("corridor", True), ("corridor", False), ("uniform", True)):
+    x = synth.corridor_torch(n, seed=synth.SEED0 + 2, kind=kind, offset=offset, device="cuda", dtype=torch.float32)
     ops.mean_seq_f32(x)
     torch.cuda.synchronize()
     t = time.perf_counter()
@@ -21,7 +21,13 @@ for offset in (True, False):
     dt = (time.perf_counter() - t) * 1e3
     ws = ops._workspace(L.pch_mean_seq_f32_ws_bytes(n), x.device)
     st = ws[:64].view(torch.int32).cpu().numpy().reshape(4, 4)[:3]
-    print(f"frame {'offset' if offset else 'local'}: {dt:.2f} ms, mean {out.cpu().numpy()}")
+    ops.set_profiling(True)
+    ops.mean_seq_f32(x)
+    torch.cuda.synchronize()
+    prof = {k: round(ms, 3) for k, ms, c in ops.get_profile()}
+    ops.set_profiling(False)
+    print(f"{kind}, frame {'offset' if offset else 'local'}: {dt:.2f} ms, mean {out.cpu().numpy()}  kernels {prof}")
     for c, name in enumerate("xyz"):
-        print(f"  column {name}: batches {st[c, 0]}, exact blocks {st[c, 2]}, descents {st[c, 3]}")
+        print(f"  column {name}: batches {st[c, 0]}, exact blocks {st[c, 2]} (of them {st[c, 1]} because the candidate "
+              f"window missed), descents {st[c, 3]}")
     del x
