@@ -574,8 +574,21 @@ static int select_passes(const float* base, int64_t n, int64_t stride, double q_
         PCH_LAUNCH("sel_hist1", (selx_hist_k<1, 2>), grid, blk, 0, s, (const float*)w.sample, ns, (int64_t)1, w.run, w.xhist, always);
         PCH_LAUNCH("sel_hist2", (selx_hist_k<2, 2>), grid, blk, 0, s, (const float*)w.sample, ns, (int64_t)1, w.run, w.xhist, always);
     }
+    // one resident round of workgroups: 32 KB of LDS each, five per CU (a 2048-workgroup grid ran as 1280 + 768:
+    // 0.191 -> 0.177 ms).  Tried and dropped (round 3): one ballot per four values and 32-bit counters (no change: the
+    // sweep is not bound by its arithmetic); per-wave staging without barriers + register prefetch (0.194 ms);
+    // 2 KB of staging per wave for 8 workgroups per CU (0.266 ms: more waves streaming shorter runs each)
     int64_t gb = ceil_div(n, SEL_TILE);
-    if (gb > 2048) gb = 2048;
+    {
+        static int per_round[PCH_MAX_DEVICES] = {};
+        const int slot = current_device_slot();
+        if (!per_round[slot]) {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            per_round[slot] = cus * 5;
+        }
+        if (gb > per_round[slot]) gb = per_round[slot];
+    }
     PCH_LAUNCH("sel_bracket", sel_bracket_k, dim3((unsigned)gb), dim3(256), 0, s, base, n, (const SelRun*)w.run, w.xhist,
                r_lo == 0 ? 1 : 0, r_hi == ns - 1 ? 1 : 0, w.br, w.cand, w.cap);
     PCH_LAUNCH("sel_bracket_fix", sel_bracket_fix_k, dim3(1), dim3(64), 0, s, w.br, fin, (unsigned long long)pi.k0,
