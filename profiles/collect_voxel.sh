@@ -3,13 +3,14 @@
 # kernel times and PMC traffic in three separate rocprofv3 runs.   bash profiles/collect_voxel.sh <tag>
 set -e -o pipefail
 tag=$1
+points=${2:-10000000}; voxel=${3:-0.2}; chunk=${4:-500000}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 tools/voxel_probe.py 10000000 0.2 500000 > $out/stats.txt 2> $out/stats.err
-rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch --output-format csv -- python3 tools/voxel_probe.py 10000000 0.2 500000 > $out/fetch.txt 2> $out/fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write --output-format csv -- python3 tools/voxel_probe.py 10000000 0.2 500000 > $out/write.txt 2> $out/write.err
-python3 profiles/summarize.py $tag $out/stats $out/pmc_fetch $out/pmc_write 10000000 voxel v0.2_chunk500k > $out/summary.txt
+rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 tools/voxel_probe.py $points $voxel $chunk > $out/stats.txt 2> $out/stats.err
+rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch --output-format csv -- python3 tools/voxel_probe.py $points $voxel $chunk > $out/fetch.txt 2> $out/fetch.err
+rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write --output-format csv -- python3 tools/voxel_probe.py $points $voxel $chunk > $out/write.txt 2> $out/write.err
+python3 profiles/summarize.py $tag $out/stats $out/pmc_fetch $out/pmc_write $points voxel v${voxel}_chunk$chunk > $out/summary.txt
 cp $out/stats.txt profiles/${tag}_probe.txt
 rm -rf $out/stats $out/pmc_fetch $out/pmc_write
 echo "[collect_voxel $tag] done"

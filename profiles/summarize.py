@@ -59,7 +59,9 @@ names = {"ms_summary_k": "mean_summary", "ms_walk_k": "mean_walk", "ms_level2_k"
          "rs_hist_k": "radix_hist", "db_gather_k": "db_gather", "db_keys_k": "db_keys",
          "sg_stats_k": "seg_stats", "db_label_k": "db_label", "db_cellbox_k": "db_cellbox",
          "db_union_face_k": "db_union0", "db_rowtab_k": "db_rowtab", "db_cellstats_k": "db_cellstats",
-         "db_cells_k": "db_cells"}
+         "db_cells_k": "db_cells", "ms_sample_k": "mean_sample", "ms_prefix_k": "mean_prefix",
+         "scan1_k<false>": "scan1", "scan1_k<true>": "scan1_popc", "db_prelabel_k": "db_prelabel",
+         "sl_hist_k": "seg_hist", "sl_scatter_k": "seg_scatter", "sl_offsets_k": "seg_offsets"}
 traffic = {"points": int(points), "kind": kind, "frame": frame, "source": tag,
            "unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, KiB->B)", "kernels": {}}
 with open(os.path.join(here, f"{tag}_pmc_traffic.csv"), "w") as f:
