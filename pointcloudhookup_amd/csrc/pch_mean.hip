@@ -239,6 +239,7 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         int S[MS_CAND];
 #pragma unroll
         for (int j = 0; j < MS_CAND; ++j) S[j] = 0;
+        int W[1 + MS_WIN] = {0, 0, 0, 0, 0};                   // the sums of the windowed path (see below)
         // ---- candidate window (wave-uniform): see the comment above ms_sample_k
         uint32_t cmask = MS_ALLCAND;
         int j0 = 1;                                            // first candidate of the window (>= 1)
@@ -281,12 +282,9 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
 #pragma unroll
                 for (int k = 0; k < MS_WIN; ++k) acc[k] += __float_as_uint(x + magic[k]);
             }
-            S[0] = (int)acc0;
+            W[0] = (int)acc0;                                  // candidate 0, then the window j0 .. j0+3
 #pragma unroll
-            for (int j = 1; j < MS_CAND; ++j) {
-#pragma unroll
-                for (int k = 0; k < MS_WIN; ++k) S[j] = (j == j0 + k) ? (int)acc[k] : S[j];
-            }
+            for (int k = 0; k < MS_WIN; ++k) W[1 + k] = (int)acc[k];
             A0 = (int)ceilf(absum * 1.00001f) + 1;
             tie &= cmask;                                      // ties of candidates that were not computed do not matter
         } else if (live) {
@@ -366,6 +364,19 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
             const auto qh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
             A0w = (long long)((((unsigned long long)qh[0] << 32) | ql[0]) + (((unsigned long long)qh[1] << 32) | ql[1]));
         }
+        MsRec* rec = &stage[wave_id()];
+        if (live && cmask != MS_ALLCAND) {
+            // five sums only: each is split into a low 16-bit and a high part per lane (|sum| <= 2^27), so that both
+            // wave totals fit 32 bits, and put together again in 64 bits
+            if (l < MS_CAND) rec->S[l] = 0;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 1 + MS_WIN; ++k) {
+                const uint32_t lo = ms_wave_all((uint32_t)W[k] & 0xFFFFu, [](uint32_t a, uint32_t b) { return a + b; });
+                const uint32_t hi = ms_wave_all((uint32_t)(W[k] >> 16), [](uint32_t a, uint32_t b) { return a + b; });
+                if (l == 0) rec->S[k == 0 ? 0 : j0 + k - 1] = ((long long)(int)hi << 16) + (long long)lo;
+            }
+        } else {
         // transposed reduction: 24 -> 12 -> 6 -> 3 values per lane while summing over the lane
         // bits 5,4,3 (|partial| <= 2^30 stays in 32 bit), then three 64-bit steps inside the 8-lane
         // groups.  Bits 5 and 4 are lane-swap steps (see ms_wave_all), bit 3 a select + DPP rotation.
@@ -391,11 +402,11 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
             t[i] = ms_add_ror64<MS_QUAD_X1>(t[i]);             // of an 8-lane group ends with the group's total
             t[i] = ms_add_ror64<MS_QUAD_X2>(t[i]);
         }
-        MsRec* rec = &stage[wave_id()];
         if ((l & 7) == 0) {
-            const int j0 = (b5 ? 12 : 0) + (b4 ? 6 : 0) + (b3 ? 3 : 0);
+            const int jb = (b5 ? 12 : 0) + (b4 ? 6 : 0) + (b3 ? 3 : 0);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) rec->S[j0 + i] = t[i];
+            for (int i = 0; i < 3; ++i) rec->S[jb + i] = t[i];
+        }
         }
         if (l < MS_CAND) rec->fix[l] = myfix;
         if (l < 18) rec->pad[l] = 0;
