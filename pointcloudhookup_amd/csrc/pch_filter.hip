@@ -661,12 +661,29 @@ struct GfState {
                                            // all folded with atomicMax so that 0 is the neutral start
 };
 
+// ---- the candidate rows of the summary pass (MsCand, pch_mean.h) -------------------------------------------------
+// May the sweep read the candidate slots instead of the tile?  Only if no survivor can be missing from them.  A row
+// survives iff fl(z - cz) > thr; the slots hold every row with z > tcand.  If tcand <= thr + cz (as real numbers: both
+// sums are exact in double), a row with z <= tcand has z - cz <= thr, and rounding is monotone with fl(thr) = thr, so
+// fl(z - cz) <= thr: it does not survive.  The same test, on the same device words, decides in gf_cand_k (go) and in
+// gf_compact_k (stand down), for both thresholds at once; a NaN anywhere fails it.
+__device__ __forceinline__ bool gf_cand_ok(const float* __restrict__ tcand, const float* __restrict__ centroid,
+                                           const float* __restrict__ scal) {
+    if (!tcand) return false;
+    if (reinterpret_cast<const uint32_t*>(tcand)[1] != 0u) return false;      // a slot overflowed (pch_mean.h)
+    const double cz = (double)centroid[2];
+    const double ta = (double)scal[1] + cz, tb = (double)scal[2] + cz;
+    const double t = (double)*tcand;
+    return t <= ta && t <= tb;
+}
+
 template <int WHICH>
 __global__ __launch_bounds__(GF_THREADS) void gf_compact_k(
     const float* __restrict__ raw, const float* __restrict__ zcol, int64_t n,
     const float* __restrict__ centroid, const float* __restrict__ scal, GfState* __restrict__ st,
     uint64_t* __restrict__ status, long long min_keep, float* __restrict__ out_points,
-    int32_t* __restrict__ out_index) {
+    int32_t* __restrict__ out_index, const float* __restrict__ tcand) {
+    if (gf_cand_ok(tcand, centroid, scal)) return;         // gf_cand_k does this sweep from the candidate slots
     __shared__ uint32_t wtot[GF_THREADS / 64];
     __shared__ uint32_t excl_sh;
     __shared__ uint32_t box[GF_THREADS / 64][6];
@@ -784,6 +801,139 @@ __global__ __launch_bounds__(GF_THREADS) void gf_compact_k(
     }
 }
 
+// The same sweep from the candidate slots: a workgroup takes 16 slots (16 384 rows of the tile, as gf_compact_k's
+// tile), a wave four of them.  ~10 % of the rows are candidates and they lie contiguously, so the sweep reads
+// ~16 B per candidate instead of the z column plus one memory line per survivor.
+constexpr int GF_CBLK = 1024;                          // rows per block of the summary
+constexpr int GF_CSLOT = MS_CAND_SLOT;                 // candidate rows a slot holds
+constexpr int GF_CT_BLKS = 64;                         // slots per workgroup: 65 536 rows of the tile - large tiles because
+                                                       // the ticket word hands out only ~88 tiles per microsecond
+constexpr int GF_CW_BLKS = GF_CT_BLKS / (GF_THREADS / 64);     // 16 slots per wave, taken in groups of four
+
+template <int WHICH>
+__global__ __launch_bounds__(GF_THREADS) void gf_cand_k(
+    const float4* __restrict__ slots, const uint32_t* __restrict__ counts, const float* __restrict__ tcand,
+    int64_t nblk, const float* __restrict__ centroid, const float* __restrict__ scal, GfState* __restrict__ st,
+    uint64_t* __restrict__ status, long long min_keep, float* __restrict__ out_points,
+    int32_t* __restrict__ out_index) {
+    __shared__ uint32_t wtot[GF_THREADS / 64];
+    __shared__ uint32_t excl_sh;
+    __shared__ uint32_t box[GF_THREADS / 64][6];
+    __shared__ unsigned long long masks[GF_THREADS / 64][GF_CW_BLKS][GF_CSLOT / 64];     // 4 KB
+    __shared__ uint32_t tile_sh;
+    if (!gf_cand_ok(tcand, centroid, scal)) return;        // gf_compact_k runs instead
+    if (WHICH == 1 && st->use_b == 0) return;
+    if (threadIdx.x == 0) tile_sh = atomicAdd(&st->ticket[WHICH], 1u);     // tile order = order of arrival (look-back)
+    __syncthreads();
+    const int64_t tile = tile_sh;
+    const float cx = centroid[0], cy = centroid[1], cz = centroid[2];
+    const float thr = scal[1 + WHICH];
+    const int w = wave_id(), l = lane_id();
+    const int64_t b0 = tile * GF_CT_BLKS + (int64_t)w * GF_CW_BLKS;
+    // Candidates come in runs: blocks next to a tower hold hundreds, most blocks few or none.  A wave therefore takes
+    // its slots one at a time with ALL rounds of the slot in flight at once (up to eight 16-byte loads per lane).
+    constexpr int NR = GF_CSLOT / 64;
+    auto load_slot = [&](int64_t b, uint32_t nc, float4 (&q)[NR]) {
+        const float4* __restrict__ slot = slots + b * GF_CSLOT;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            q[r].x = q[r].y = q[r].z = q[r].w = 0.0f;
+            if ((uint32_t)(r * 64) < nc) {                 // wave-uniform: rounds beyond the slot's count cost nothing
+                const uint32_t i = r * 64 + l;
+                if (i < nc) q[r] = slot[i];
+            }
+        }
+    };
+    uint32_t ncs[GF_CW_BLKS];
+#pragma unroll
+    for (int kb = 0; kb < GF_CW_BLKS; ++kb) ncs[kb] = (b0 + kb) < nblk ? counts[b0 + kb] : 0u;
+    uint32_t run = 0;
+#pragma unroll 1
+    for (int kb = 0; kb < GF_CW_BLKS; ++kb) {
+        const uint32_t nc = ncs[kb];
+        if (nc == 0) continue;                             // wave-uniform
+        float4 q[NR];
+        load_slot(b0 + kb, nc, q);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if ((uint32_t)(r * 64) >= nc) break;
+            const uint32_t i = r * 64 + l;
+            const bool keep = i < nc && (q[r].z - cz) > thr;            // points = raw_points - centroid (float32)
+            const unsigned long long m = __ballot(keep);
+            if (l == 0) masks[w][kb][r] = m;
+            run += (uint32_t)__popcll(m);
+        }
+    }
+    if (l == 0) wtot[w] = run;
+    __syncthreads();
+    const uint32_t T = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    if (w == 0) {
+        const uint32_t e0 = gf_lookback(status, tile, T);
+        const bool lb_failed = e0 == GF_LB_FAILED;
+        const uint32_t e = lb_failed ? 0u : e0;              // prefix 0 keeps the writes below inside the output
+        if (l == 0) {
+            excl_sh = e;
+            if (lb_failed) {
+                atomicOr(&st->failed, 1u);
+            } else if (tile == (int64_t)gridDim.x - 1) {     // the last tile knows the total: it also decides
+                st->total[WHICH] = e + T;                    // whether the fallback threshold applies
+                if (WHICH == 0) st->use_b = ((long long)(e + T) < min_keep) ? 1u : 0u;
+            }
+        }
+    }
+    __syncthreads();
+    if (T == 0) return;                                    // workgroup-uniform
+    uint32_t woff = excl_sh;
+    for (int w2 = 0; w2 < w; ++w2) woff += wtot[w2];
+    uint32_t lo[3] = {0u, 0u, 0u}, hi[3] = {0u, 0u, 0u};  // lo holds ~ordered(min)
+    const uint64_t lt = lanemask_lt();
+#pragma unroll 1
+    for (int kb = 0; kb < GF_CW_BLKS; ++kb) {
+        const uint32_t nc = ncs[kb];
+        if (nc == 0) continue;
+        const int64_t b = b0 + kb;
+        float4 q[NR];
+        load_slot(b, nc, q);                               // the same lines again: they are in L2 now
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if ((uint32_t)(r * 64) >= nc) break;
+            const unsigned long long m = masks[w][kb][r];
+            if (m == 0) continue;
+            if ((m >> l) & 1ull) {
+                const float4 c4 = q[r];
+                const float v[3] = {c4.x - cx, c4.y - cy, c4.z - cz};
+                const int64_t o = (int64_t)woff + (uint32_t)__popcll(m & lt);
+                out_points[3 * o + 0] = v[0];
+                out_points[3 * o + 1] = v[1];
+                out_points[3 * o + 2] = v[2];
+                if (out_index) out_index[o] = (int32_t)(b * GF_CBLK + (int64_t)__float_as_uint(c4.w));
+                if (fabsf(v[0]) < INFINITY && fabsf(v[1]) < INFINITY && fabsf(v[2]) < INFINITY) {   // NaN/inf rows
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const uint32_t kk = f32_ordered(v[a]);
+                        lo[a] = ~kk > lo[a] ? ~kk : lo[a];
+                        hi[a] = kk > hi[a] ? kk : hi[a];
+                    }
+                }
+            }
+            woff += (uint32_t)__popcll(m);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = wave_reduce_max(lo[a]);
+        hi[a] = wave_reduce_max(hi[a]);
+        if (l == 0) { box[w][a] = lo[a]; box[w][3 + a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        uint32_t v = box[0][a];
+        for (int w2 = 1; w2 < GF_THREADS / 64; ++w2) v = box[w2][a] > v ? box[w2][a] : v;
+        if (v) atomicMax(&st->slots[WHICH][tile % GF_SLOTS][a], v);
+    }
+}
+
 // publishes the scalars, the count and the bounding box of the sweep that counts
 __global__ void gf_finalize_k(const GfState* __restrict__ st, const float* __restrict__ centroid,
                               const float* __restrict__ scal, float* __restrict__ out_scalars,
@@ -817,6 +967,7 @@ struct GfWs {
     GfState*  st;
     uint64_t* status;            // [2][tiles] look-back words of the two sweeps
     size_t    clear_bytes;       // st .. end of status: zeroed before the sweeps
+    MsCand    cand;              // candidate rows emitted by the summary pass (see gf_cand_k)
 };
 static void gf_plan(Arena& a, int64_t n, GfWs& w) {
     const int64_t nb = ceil_div(n > 0 ? n : 1, GF_TILE);
@@ -828,6 +979,13 @@ static void gf_plan(Arena& a, int64_t n, GfWs& w) {
     w.st = a.take<GfState>(1);
     w.status = a.take<uint64_t>(2 * nb);
     w.clear_bytes = a.off - st_off;
+    const int64_t nblk = ceil_div(n > 0 ? n : 1, GF_CBLK);
+    w.cand.tcand = a.take<float>(4);
+    w.cand.counts = a.take<uint32_t>(nblk);
+    w.cand.zsample = a.take<float>(nblk);
+    w.cand.slots = a.take<float4>(nblk * MS_CAND_SLOT);    // 8 KB per 1024-row block
+    w.cand.pct = 0.0;
+    w.cand.add = 0.0f;
 }
 
 }  // namespace pch
@@ -1012,7 +1170,8 @@ extern "C" int pch_filter_gt_f32(const float* raw, int64_t n, const float* centr
     PCH_HIP_TRY(hipMemsetAsync(st, 0, a.off - st_off, s));
     PCH_LAUNCH("gf_zcol", gf_zcol_k, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, raw, n, zcol);
     PCH_LAUNCH("gf_compact", gf_compact_k<0>, dim3((unsigned)nb), dim3(GF_THREADS), 0, s, raw, (const float*)zcol, n,
-               (const float*)scal, (const float*)(scal + 4), st, status, (long long)0, out_points, out_index);
+               (const float*)scal, (const float*)(scal + 4), st, status, (long long)0, out_points, out_index,
+               (const float*)nullptr);
     PCH_LAUNCH("gf_count_out", gf_count_out_k, dim3(1), dim3(64), 0, s, (const GfState*)st, out_count, out_aabb);
     PCH_HIP_TRY(hipStreamSynchronize(s));               // `hs` lives on this stack frame
     return PCH_OK;
@@ -1041,26 +1200,45 @@ extern "C" int pch_ground_filter_f32(const float* raw, int64_t n, double pct, fl
     if (a.overflow) { set_error("workspace too small: need %zu bytes", a.off); return PCH_ERR_WORKSPACE; }
     const int64_t nb = ceil_div(n, GF_TILE);
 
+    // candidate rows for the sweep: raw z above (estimated percentile + the smaller offset - 0.5 m), emitted by the summary
+    w.cand.pct = pct;
+    w.cand.add = (offset < fallback_offset ? offset : fallback_offset) - 0.5f;
+    bool cand_made = false;
     SideStream& ss = side_stream();
     if (ss.ok) {
-        PCH_TRY(mean_seq_launch(raw, n, w.centroid, w.ms, w.zcol, s, ss.ev_fork));
+        PCH_TRY(mean_seq_launch(raw, n, w.centroid, w.ms, w.zcol, s, ss.ev_fork, nullptr, MS_DIVIDE_BY_N, MS_PHASE_BOTH,
+                                &w.cand, &cand_made));
         PCH_HIP_TRY(hipStreamWaitEvent(ss.s, ss.ev_fork, 0));
         PCH_TRY(select_passes(w.zcol, n, 1, pct, w.sel, ss.s));
         PCH_HIP_TRY(hipEventRecord(ss.ev_join, ss.s));
         PCH_HIP_TRY(hipStreamWaitEvent(s, ss.ev_join, 0));
     } else {
-        PCH_TRY(mean_seq_launch(raw, n, w.centroid, w.ms, w.zcol, s));
+        PCH_TRY(mean_seq_launch(raw, n, w.centroid, w.ms, w.zcol, s, nullptr, nullptr, MS_DIVIDE_BY_N, MS_PHASE_BOTH,
+                                &w.cand, &cand_made));
         PCH_TRY(select_passes(w.zcol, n, 1, pct, w.sel, s));
     }
     PCH_TRY(select_lerp(n, w.centroid + 2, pct, offset, fallback_offset, w.sel, s));
     PCH_HIP_TRY(hipMemsetAsync(w.st, 0, w.clear_bytes, s));
     const dim3 grid((unsigned)nb), blk(GF_THREADS);
+    const float* tcand = cand_made ? (const float*)w.cand.tcand : (const float*)nullptr;
+    if (cand_made) {
+        // from the candidate slots when the device-side guard allows it (gf_cand_ok); the sweeps over the tile below
+        // then return at once - and the other way round.  Same tiles, same tickets, same look-back words.
+        const int64_t nblk = ceil_div(n, GF_CBLK);
+        const dim3 cgrid((unsigned)ceil_div(nblk, GF_CT_BLKS));
+        PCH_LAUNCH("gf_cand", gf_cand_k<0>, cgrid, blk, 0, s, (const float4*)w.cand.slots, (const uint32_t*)w.cand.counts,
+                   tcand, nblk, (const float*)w.centroid, (const float*)w.sel.scal, w.st, w.status, (long long)min_keep,
+                   out_points, out_index);
+        PCH_LAUNCH("gf_cand_fb", gf_cand_k<1>, cgrid, blk, 0, s, (const float4*)w.cand.slots,
+                   (const uint32_t*)w.cand.counts, tcand, nblk, (const float*)w.centroid, (const float*)w.sel.scal, w.st,
+                   w.status + nb, (long long)min_keep, out_points, out_index);
+    }
     PCH_LAUNCH("gf_compact", gf_compact_k<0>, grid, blk, 0, s, raw, (const float*)w.zcol, n,
                (const float*)w.centroid, (const float*)w.sel.scal, w.st, w.status, (long long)min_keep, out_points,
-               out_index);
+               out_index, tcand);
     PCH_LAUNCH("gf_compact_fb", gf_compact_k<1>, grid, blk, 0, s, raw, (const float*)w.zcol, n,
                (const float*)w.centroid, (const float*)w.sel.scal, w.st, w.status + nb, (long long)min_keep, out_points,
-               out_index);
+               out_index, tcand);
     PCH_LAUNCH("gf_finalize", gf_finalize_k, dim3(1), dim3(64), 0, s, (const GfState*)w.st,
                (const float*)w.centroid, (const float*)w.sel.scal, out_scalars, out_count, out_aabb);
     return PCH_OK;

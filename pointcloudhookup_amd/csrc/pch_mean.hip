@@ -111,7 +111,7 @@ __device__ __forceinline__ uint32_t ms_tie_bit(float x) {
 struct MsPred { double pre, rowsum, meanabs; };          // per (column, level-2 row)
 
 __global__ __launch_bounds__(64) void ms_sample_k(const float* __restrict__ xyz, int64_t n, int64_t nb, int64_t nb2,
-                                                  MsPred* __restrict__ pred) {
+                                                  MsPred* __restrict__ pred, float* __restrict__ zsample) {
     const int64_t row = blockIdx.x;
     const int l = lane_id();
     const int64_t blk = row * 64 + l;
@@ -125,6 +125,7 @@ __global__ __launch_bounds__(64) void ms_sample_k(const float* __restrict__ xyz,
         const Row3 q = reinterpret_cast<const Row3*>(xyz)[p];
         v[0] = q.x; v[1] = q.y; v[2] = q.z;
         have = 1;
+        if (zsample) zsample[blk] = q.z;
     }
     const int64_t first = row * 64 * MSB;
     const double cnt_row = (double)((n - first) < (int64_t)64 * MSB ? (n - first) : (int64_t)64 * MSB);
@@ -149,10 +150,99 @@ __global__ __launch_bounds__(64) void ms_sample_k(const float* __restrict__ xyz,
 
 // exclusive prefix of the row sums per column (one 1024-thread workgroup per column: a block scan per 1024 rows),
 // starting from the incoming running sum
+// Block 3 (when launched): a deliberately LOW estimate of the height filter's raw-z threshold from the sampled z values
+// (one per block): the lower edge of the 2^-11-wide key bin that holds the sample's pct-quantile, found by two LDS
+// histogram passes over the order-preserving keys, plus `add`.  Only an estimate: what it is used for is checked
+// against the exact threshold later (gf_cand_k).
+__device__ void ms_zestimate(const float* __restrict__ zs, int64_t ns, double pct, float add, float* __restrict__ tcand) {
+    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t pick_bin, pick_below, total_sh;
+    const int l = lane_id(), w = wave_id();
+    // most samples share a handful of bins (flat ground): lanes that hold the leader's bin add ONCE for all of them
+    auto add_bin = [&](bool in, uint32_t bin) {
+        const unsigned long long act = __ballot(in);
+        if (!act) return;
+        const int lead = (int)__builtin_ctzll(act);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, lead);
+        const unsigned long long same = __ballot(in && bin == b0);
+        if (l == lead) atomicAdd(&hist[b0], (uint32_t)__popcll(same));
+        if (in && bin != b0) atomicAdd(&hist[bin], 1u);
+    };
+    // bin that holds `rank` and the count below it: every thread owns two bins, block-wide exclusive scan
+    auto scan_pick = [&](uint32_t rank) {
+        __syncthreads();
+        const uint32_t h0 = hist[2 * threadIdx.x], h1 = hist[2 * threadIdx.x + 1];
+        const uint32_t incl = wave_scan_incl(h0 + h1);
+        if (l == 63) wsum[w] = incl;
+        __syncthreads();
+        uint32_t before = incl - (h0 + h1);
+        for (int k = 0; k < w; ++k) before += wsum[k];
+        if (rank >= before && rank < before + h0) { pick_bin = 2 * threadIdx.x; pick_below = before; }
+        else if (rank >= before + h0 && rank < before + h0 + h1) { pick_bin = 2 * threadIdx.x + 1; pick_below = before + h0; }
+        __syncthreads();
+    };
+    for (int j = threadIdx.x; j < 2048; j += 1024) hist[j] = 0;
+    if (threadIdx.x == 0) { total_sh = 0; pick_bin = 2047; pick_below = 0; }
+    __syncthreads();
+    // every 4th sample is plenty for an estimate (24 k values at 100 M points); 16 loads in flight per thread
+    constexpr int EST_STRIDE = 4, EST_BATCH = 16;
+    const int64_t ne = (ns + EST_STRIDE - 1) / EST_STRIDE;
+    uint32_t mine = 0;
+    for (int64_t i0 = 0; i0 < ne; i0 += 1024 * EST_BATCH) {   // workgroup-uniform trip count (ballots inside)
+        float zb[EST_BATCH];
+#pragma unroll
+        for (int u = 0; u < EST_BATCH; ++u) {
+            const int64_t i = i0 + u * 1024 + threadIdx.x;
+            zb[u] = i < ne ? zs[i * EST_STRIDE] : NAN;
+        }
+#pragma unroll
+        for (int u = 0; u < EST_BATCH; ++u) {
+            const bool in = zb[u] == zb[u];
+            add_bin(in, f32_ordered(zb[u]) >> 21);
+            mine += in ? 1u : 0u;
+        }
+    }
+    mine = wave_reduce_add(mine);
+    if (l == 0) atomicAdd(&total_sh, mine);
+    __syncthreads();
+    const uint32_t total = total_sh;
+    if (threadIdx.x == 0) reinterpret_cast<uint32_t*>(tcand)[1] = 0u;           // overflow word of the slots
+    if (total == 0) { if (threadIdx.x == 0) *tcand = -INFINITY; return; }       // no estimate: every row is a candidate
+    uint32_t rank = (uint32_t)((double)(total - 1) * (pct / 100.0));
+    scan_pick(rank);
+    const uint32_t top = pick_bin;
+    rank -= pick_below;
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2048; j += 1024) hist[j] = 0;
+    if (threadIdx.x == 0) { pick_bin = 2047; pick_below = 0; }
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < ne; i0 += 1024 * EST_BATCH) {
+        float zb[EST_BATCH];
+#pragma unroll
+        for (int u = 0; u < EST_BATCH; ++u) {
+            const int64_t i = i0 + u * 1024 + threadIdx.x;
+            zb[u] = i < ne ? zs[i * EST_STRIDE] : NAN;
+        }
+#pragma unroll
+        for (int u = 0; u < EST_BATCH; ++u) {
+            const uint32_t k = f32_ordered(zb[u]);
+            add_bin(zb[u] == zb[u] && (k >> 21) == top, (k >> 10) & 2047u);
+        }
+    }
+    scan_pick(rank);
+    if (threadIdx.x == 0) {
+        const uint32_t key = (top << 21) | (pick_bin << 10);       // lower edge of the bin
+        *tcand = f32_unordered(key) + add;
+    }
+}
+
 __global__ __launch_bounds__(1024) void ms_prefix_k(MsPred* __restrict__ pred, int64_t nb2,
-                                                    const float* __restrict__ sum_in) {
+                                                    const float* __restrict__ sum_in, const float* __restrict__ zs,
+                                                    int64_t ns, double pct, float add, float* __restrict__ tcand) {
     __shared__ double wsum[16];
     __shared__ double carry_sh;
+    if (blockIdx.x == 3) { ms_zestimate(zs, ns, pct, add, tcand); return; }
     const int c = blockIdx.x;
     const int l = lane_id(), w = wave_id();
     if (threadIdx.x == 0) carry_sh = sum_in ? (double)sum_in[c] : 0.0;
@@ -183,7 +273,9 @@ __device__ __forceinline__ int ms_exp2_floor(double x) {        // floor(log2 |x
 __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __restrict__ xyz, int64_t n,
                                                              int64_t nb, MsRec* __restrict__ recs,
                                                              float* __restrict__ zcol,
-                                                             const MsPred* __restrict__ pred, int64_t nb2) {
+                                                             const MsPred* __restrict__ pred, int64_t nb2,
+                                                             float4* __restrict__ cslots, uint32_t* __restrict__ ccounts,
+                                                             const float* __restrict__ tcand) {
     __shared__ __attribute__((aligned(16))) float lds[MS_WAVES][MSB * 3];
     __shared__ MsRec stage[MS_WAVES];                    // a record is assembled here, stored as whole lines
     const int64_t blk = (int64_t)blockIdx.x * MS_WAVES + wave_id();
@@ -207,6 +299,31 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         for (int i = 0; i < MS_PER; ++i) {
             const int p = i * 64 + l;
             if (p < cnt) zcol[p0 + p] = tile[3 * p + 2];
+        }
+    }
+    if (cslots) {
+        // candidate rows of the height filter (MsCand): raw z above the low threshold estimate, kept in file order
+        const float tc = *tcand;
+        float4* slot = cslots + blk * MS_CAND_SLOT;
+        uint32_t at = 0;
+#pragma unroll
+        for (int i = 0; i < MS_PER; ++i) {
+            const int p = i * 64 + l;
+            const float z = tile[3 * p + 2];
+            const bool take = p < cnt && z > tc;
+            const unsigned long long m = __ballot(take);
+            const uint32_t pos = at + (uint32_t)__popcll(m & lanemask_lt());
+            if (take && pos < (uint32_t)MS_CAND_SLOT) {
+                float4 q;
+                q.x = tile[3 * p]; q.y = tile[3 * p + 1]; q.z = z; q.w = __uint_as_float((uint32_t)p);
+                slot[pos] = q;
+            }
+            at += (uint32_t)__popcll(m);
+        }
+        if (l == 0) {
+            ccounts[blk] = at < (uint32_t)MS_CAND_SLOT ? at : (uint32_t)MS_CAND_SLOT;
+            if (at > (uint32_t)MS_CAND_SLOT)               // more candidates than the slot holds: the sweep reads the tile
+                atomicOr(reinterpret_cast<uint32_t*>(const_cast<float*>(tcand)) + 1, 1u);
         }
     }
     const bool b5 = (l & 32) != 0, b4 = (l & 16) != 0, b3 = (l & 8) != 0;
@@ -853,7 +970,9 @@ void ms_plan(Arena& a, int64_t n, MsWs& w) {
 }
 
 int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zcol, hipStream_t s,
-                    hipEvent_t ev_zcol, const float* sum_in, int64_t divide_n, int phase) {
+                    hipEvent_t ev_zcol, const float* sum_in, int64_t divide_n, int phase, const MsCand* cand,
+                    bool* cand_made) {
+    if (cand_made) *cand_made = false;
     const int64_t nb = n > 0 ? ceil_div(n, MSB) : 0;
     const int64_t nb2 = ceil_div(nb, 64);
     if (n > 0 && phase != MS_PHASE_WALK) {
@@ -862,12 +981,20 @@ int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zco
         static const bool no_predict = getenv("PCH_MEAN_NO_PREDICT") != nullptr;      // tuning toggle
         const MsPred* pred = nullptr;
         if (!no_predict && phase == MS_PHASE_BOTH && nb2 >= 2) {
-            PCH_LAUNCH("mean_sample", ms_sample_k, dim3((unsigned)nb2), dim3(64), 0, s, xyz, n, nb, nb2, w.pred);
-            PCH_LAUNCH("mean_prefix", ms_prefix_k, dim3(3), dim3(1024), 0, s, w.pred, nb2, sum_in);
+            static const bool no_cand = getenv("PCH_GF_NO_CAND") != nullptr;              // tuning toggle
+            const bool mk = cand && !no_cand;
+            PCH_LAUNCH("mean_sample", ms_sample_k, dim3((unsigned)nb2), dim3(64), 0, s, xyz, n, nb, nb2, w.pred,
+                       mk ? cand->zsample : (float*)nullptr);
+            PCH_LAUNCH("mean_prefix", ms_prefix_k, dim3(mk ? 4 : 3), dim3(1024), 0, s, w.pred, nb2, sum_in,
+                       mk ? (const float*)cand->zsample : (const float*)nullptr, nb, mk ? cand->pct : 0.0,
+                       mk ? cand->add : 0.0f, mk ? cand->tcand : (float*)nullptr);
             pred = w.pred;
+            if (mk && cand_made) *cand_made = true;
         }
+        const bool emit = cand && cand_made && *cand_made;
         PCH_LAUNCH("mean_summary", ms_summary_k, dim3((unsigned)ceil_div(nb, MS_WAVES)), dim3(64 * MS_WAVES),
-                   0, s, xyz, n, nb, w.rec, zcol, pred, nb2);
+                   0, s, xyz, n, nb, w.rec, zcol, pred, nb2, emit ? cand->slots : (float4*)nullptr,
+                   emit ? cand->counts : (uint32_t*)nullptr, emit ? (const float*)cand->tcand : (const float*)nullptr);
         if (ev_zcol) PCH_HIP_TRY(hipEventRecord(ev_zcol, s));
         PCH_LAUNCH("mean_level2", ms_level2_k, dim3((unsigned)(3 * nb2)), dim3(256), 0, s,
                    (const MsRec*)w.rec, nb, nb2, w.hdr2, w.rows2);

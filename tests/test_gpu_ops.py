@@ -275,6 +275,53 @@ def test_ground_filter_matches_numpy(cuda, n, kind, offset):
         np.testing.assert_array_equal(got["aabb"], np.concatenate([f.min(0), f.max(0)]))
 
 
+@pytest.mark.parametrize("case", ["slots", "slot_overflow", "estimate_too_high", "fallback_threshold", "nan_rows"])
+def test_ground_filter_candidate_slots_and_their_fallbacks(cuda, case):
+    """From 131 072 rows on, the centroid pass also emits the candidate rows of the filter (raw z above a LOW estimate
+    of the threshold, 256 per 1024-row block) and the sweep reads those instead of the tile - but only when a
+    device-side guard proves that no survivor can be missing (gf_cand_ok).  Every route must give numpy's result bit
+    for bit: the slots; a block with more candidates than its slot holds (a tower in file order: overflow word ->
+    the sweep over the tile); an estimate that is not low enough (threshold far below the sampled quantile + margin:
+    guard fails -> the sweep over the tile); the `< 1000 survivors` fallback threshold; NaN / inf rows."""
+    rng = np.random.default_rng(11)
+    n = 400_003
+    pts = np.column_stack([rng.uniform(0, 2000, n), rng.uniform(0, 100, n), rng.normal(0, 0.05, n)])
+    tall = rng.random(n) < 0.08
+    pts[tall, 2] = rng.uniform(4, 40, tall.sum())
+    if case == "slot_overflow":
+        pts[200_000:206_000, 2] = rng.uniform(10, 30, 6000)          # six whole blocks of candidates in file order
+    if case == "estimate_too_high":
+        # a quarter of the rows far below the rest: the 25th percentile sits on a cliff of the distribution, so the
+        # exact value may lie well below the sampled estimate - whichever route is taken must be exact
+        low = rng.random(n) < 0.2503
+        pts[low, 2] = rng.uniform(-500, -400, low.sum())
+    if case == "fallback_threshold":
+        pts[:, 2] = rng.normal(0, 0.7, n)                             # fewer than 1000 rows above +3.0
+        pts[:300, 2] += 10.0
+    if case == "nan_rows":                                             # non-finite x / y on rows that survive
+        pts[[12345, 222222, 333333], 2] = 20.0
+        pts[12345, 0] = np.nan
+        pts[222222, 1] = np.inf
+        pts[333333, 1] = -np.inf
+    raw = (pts + np.array([437000.0, 3139000.0, 80.0])).astype(np.float32)
+    ref = ogf.ground_filter(raw)
+    got = ops.ground_filter(_dev(raw, cuda))
+    assert got["used_fallback"] == ref["used_fallback"]
+    if case not in ("nan_rows",):
+        assert ref["used_fallback"] == (case == "fallback_threshold")
+    np.testing.assert_array_equal(got["centroid"].view(np.uint32), ref["centroid"].view(np.uint32))
+    assert np.float32(got["threshold"]).view(np.uint32) == ref["threshold"].view(np.uint32)
+    assert got["count"] == len(ref["filtered"])
+    gp, f = got["points"].cpu().numpy(), ref["filtered"]
+    nanpos = np.isnan(f)
+    np.testing.assert_array_equal(np.isnan(gp), nanpos)               # NaN - c is NaN on both sides (payload bits aside)
+    np.testing.assert_array_equal(gp.view(np.uint32)[~nanpos], f.view(np.uint32)[~nanpos])
+    np.testing.assert_array_equal(got["index"].cpu().numpy(), np.flatnonzero(ref["keep"]))
+    fin = np.isfinite(f).all(axis=1)
+    if fin.any():                            # (a NaN / inf in a column makes that column's centroid, hence every row, non-finite)
+        np.testing.assert_array_equal(got["aabb"], np.concatenate([f[fin].min(0), f[fin].max(0)]))
+
+
 # ------------------------------------------------------------------------------ stage C
 def _blobs(rng, n, k, spread, sigma, clutter):
     per = (n - clutter) // k
