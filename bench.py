@@ -129,8 +129,9 @@ def launch_ranks(args, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["PCH_BENCH_PARENT_TORCH"] = str("torch" in sys.modules)     # must be False: the parent stays off the GPU
-    if env.get("PCH_BENCH_SINGLE_DEVICE"):
-        env.setdefault("PCH_DIST_BACKEND", "gloo")          # RCCL refuses two ranks on one device
+    if env.get("PCH_BENCH_SINGLE_DEVICE") and not env.get("PCH_BENCH_PROBE_RCCL"):
+        env.setdefault("PCH_DIST_BACKEND", "gloo")          # RCCL refuses two ranks on one device (PCH_BENCH_PROBE_RCCL=1:
+                                                            # let the probe find that out and fall back - a test of it)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -260,7 +261,7 @@ def run_tiled(points_total, kind, frame, rank, world, dev, steps, warmup, seed, 
                         f"DBSCAN(eps={EPS:g}, min_samples={MIN_POINTS}) per tile + cross-tile label reconciliation "
                         "(BASELINE configs[3] at 400 M / 8 GPUs)",
             "points_total": int(points_total), "ranks_seen": int(dist.get_world_size()) if world > 1 else 1,
-            "backend": dist.get_backend() if world > 1 else "none",
+            "backend": tiles.exchange_backend(),
             "devices": "one GPU shared by all ranks (rehearsal)" if os.environ.get("PCH_BENCH_SINGLE_DEVICE") else "one GPU per rank",
             "steps": steps, "ms_per_step": round(1e3 * ph[0] / steps, 3),
             "Mpts_per_s": round(points_total * steps / ph[0] / 1e6, 1),

@@ -31,23 +31,72 @@ import torch
 import torch.distributed as dist
 
 
+# The group the exchanges of this module use when the caller passes group=None: None = the default group.  With
+# automatic backend choice on GPUs the DEFAULT group is gloo (it always comes up) and the exchanges run on an RCCL
+# group that was probed first (init_from_env) - a node whose RCCL does not initialise degrades to gloo exchanges
+# (a few KB each) instead of losing the run.
+_EXCHANGE_GROUP = None
+
+
+def _pg(group):
+    return group if group is not None else _EXCHANGE_GROUP
+
+
+def exchange_backend():
+    """'nccl' (= RCCL on ROCm), 'gloo' or 'none': what carries the exchanges of this module by default."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return "none"
+    return dist.get_backend(_EXCHANGE_GROUP)
+
+
 def init_from_env(backend=None, timeout_s=None):
     """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* when WORLD_SIZE > 1.
+    backend: "nccl" / "gloo" (also env PCH_DIST_BACKEND) = that backend for everything.  None on a GPU node: the
+    default group is gloo and an RCCL group over all ranks is PROBED - created, one small all-reduce on the device,
+    the outcome agreed over gloo; if every rank succeeded the exchanges of this module use it (exchange_backend() ==
+    'nccl'), otherwise they stay on gloo and rank 0 says so.
     ``timeout_s`` bounds every collective (a rank that died leaves the others waiting at most that long).
     Returns (rank, world, local_rank)."""
+    global _EXCHANGE_GROUP
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        if backend is None:          # RCCL over xGMI on GPUs; PCH_DIST_BACKEND=gloo for CPU rehearsals
-            backend = os.environ.get("PCH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
-            torch.cuda.set_device(local)
         kw = {}
         if timeout_s:
             import datetime
             kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        if backend is None:
+            backend = os.environ.get("PCH_DIST_BACKEND")
+        if backend is not None or not torch.cuda.is_available():
+            backend = backend or "gloo"
+            if backend == "nccl":
+                torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+            _EXCHANGE_GROUP = None
+            return rank, world, local
+        devi = 0 if os.environ.get("PCH_BENCH_SINGLE_DEVICE") else local     # rehearsal: all ranks on device 0
+        torch.cuda.set_device(devi)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, **kw)
+        ok, why, g = 1, "", None
+        try:
+            g = dist.new_group(ranks=list(range(world)), backend="nccl", **kw)
+            t = torch.ones(1, device=torch.device("cuda", devi))
+            dist.all_reduce(t, group=g)
+            torch.cuda.synchronize()
+            if int(t.item()) != world:
+                ok, why = 0, f"all_reduce gave {t.item()} for {world} ranks"
+        except Exception as e:                              # e.g. two ranks on one device, IPC not available
+            ok, why = 0, f"{type(e).__name__}: {e}"
+        flag = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)         # over gloo: every rank takes the same branch
+        if int(flag.item()) == 1:
+            _EXCHANGE_GROUP = g
+        else:
+            _EXCHANGE_GROUP = None
+            if why:
+                print(f"[pch tiles] rank {rank}: RCCL probe failed ({why.splitlines()[0][:200]}); exchanges stay on gloo",
+                      flush=True)
     return rank, world, local
 
 
@@ -70,6 +119,7 @@ def reconcile(nclusters, table, group=None):
     Returns (label_offset int, total int, global_table [total, C] on the same device,
              owner int64 [total] = rank that produced each row).
     """
+    group = _pg(group)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         owner = torch.zeros((int(nclusters),), dtype=torch.int64, device=table.device)
         return 0, int(nclusters), table[: int(nclusters)], owner
@@ -268,6 +318,7 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
     (global row, local cluster) pairs of the strip at the tile's upper edge, one pair per grid cell
     (pch_dbscan_strip_pairs_i32); (2) the piece-to-piece links the right-hand tile found by looking those rows up in
     its own labels.  The same union (scipy connected_components) then runs on every rank."""
+    group = _pg(group)
     import time
     t_start = time.perf_counter()
     fit = fit or HipFit(eps, min_samples)
@@ -407,6 +458,7 @@ def shared_percentile(values, q_percent, sub=None, select=None, group=None):
     values: this rank's 1-D float32 values (device tensor for the HIP passes); sub: float32 subtracted from the
     two order statistics before the lerp (the centroid's z: x -> fl(x - sub) is monotone, so the select runs on
     the raw values).  Returns np.float32."""
+    group = _pg(group)
     select = select or HipSelect()
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
@@ -496,6 +548,7 @@ def sharded_centroid(own_rows, total_n, shard=None, group=None, timings=None):
     builds the summary tables of its own rows first and at the same time (they do not depend on the incoming
     sums); only the short serial walks are chained.  Replaces utils/tower_extraction.py:63 for a cloud whose
     file-order shards live on different GPUs.  Returns np.float32 [3] (host)."""
+    group = _pg(group)
     if int(total_n) == 0:                                  # np.mean of an empty array: 0 / 0 (every rank knows total_n)
         return np.full(3, np.nan, dtype=np.float32)
     shard = shard or HipMeanShard(own_rows)
@@ -528,6 +581,7 @@ def global_rows(local_row, n_own, group=None):
     """Global row numbers of a tile whose rows are numbered relative to its first OWNED row: the owned blocks follow
     each other in rank order, so the base is the exclusive prefix of n_own over the ranks (one all_gather of one
     integer per rank - what reading the LAS headers of a tile stream gives).  Returns (rows int64, total rows)."""
+    group = _pg(group)
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     if not multi:
         return local_row, int(n_own)
@@ -557,6 +611,7 @@ def tiled_step(tile, tile_rows, own, total_n, x_lo, x_hi, eps=8.0, min_samples=8
       filter     ops.filter_gt on tile + halo with those values    :64,84
       cluster    tiles.cluster_tiled (global DBSCAN, no 50 000-row chunks: north star / SURVEY 8e-ii)
     """
+    group = _pg(group)
     import time
     from . import ops
     t0 = time.perf_counter()

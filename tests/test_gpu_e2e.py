@@ -269,6 +269,27 @@ def test_bench_tiled_mode_equals_the_single_gpu_run(cuda, world):
     assert set(t["phase_ms_max_over_ranks"]) == {"centroid_chain+threshold+filter", "local_fit", "reconciliation"}
 
 
+def test_rccl_probe_failure_degrades_to_gloo(cuda):
+    """tiles.init_from_env with automatic backend choice: the default group is gloo and an RCCL group is PROBED.  Two
+    ranks on this one GPU make RCCL refuse (duplicate device) - the run must go on with gloo exchanges and still
+    reproduce the single-GPU result; the line says which backend carried the exchange."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PCH_BENCH_SINGLE_DEVICE="1", PCH_BENCH_PROBE_RCCL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PCH_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "tiled",
+                        "--points", "12000000", "--steps", "2", "--warmup", "1", "--verify"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["tiled"]["verified_against_single_gpu_run"] is True
+    assert out["tiled"]["backend"] == "gloo" and out["tiled"]["ranks_seen"] == 2
+    assert "RCCL probe failed" in r.stdout + r.stderr
+
+
 def test_dbscan_strip_pairs_cover_every_strip_core_point(cuda):
     """pch_dbscan_strip_pairs_i32: one (row, cluster) pair per grid cell with a core point in the strip.  Every core
     point of the strip must be within eps of the representative of ITS cluster's pairs (same cell => within eps), the
