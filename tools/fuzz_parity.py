@@ -100,4 +100,12 @@ while time.time() < t_end:
         g2, l2, k2, perm, offs, st = ops.tower_clusters(torch.from_numpy(pts + ref["centroid"]).to(dev), eps, ms,
                                                         chunk if chunk else 50000)
         assert g2["count"] <= m
+        # the fused call (cluster boxes gathered by the label kernels) against the separate stage calls
+        if g2["count"] >= 2:
+            l3, _, k3 = ops.dbscan(g2["points"], eps, ms, chunk if chunk else 50000, aabb=g2["aabb"])
+            assert k3 == k2 and torch.equal(l3, l2), ("fused labels", n, m, it)
+            p3, o3, s3 = ops.segment_by_label(l3, g2["points"], k3)
+            assert torch.equal(p3, perm) and torch.equal(o3, offs), ("fused grouping", n, m, it)
+            assert np.array_equal(s3.cpu().numpy().view(np.uint32), st.cpu().numpy().view(np.uint32)), ("fused boxes", n, m, it)
+            stats["fused"] = stats.get("fused", 0) + 1
 print("fuzz ok", stats, "iterations", it)
