@@ -573,7 +573,8 @@ __device__ __forceinline__ int ms_pad(int i) { return i + (i >> 4); }   // LDS b
 // the sum, a binade or sign change, a non-finite value) is added element by element, and the
 // rest of the block is redone at the new binade.
 __device__ __forceinline__ uint32_t ms_block_exact(const float* __restrict__ xyz, int64_t n, int c,
-                                                   int64_t blk, uint32_t sb, float* stage, int& serial_len) {
+                                                   int64_t blk, uint32_t sb, float* stage, int& serial_len,
+                                                   int* dbg) {
     const int l = lane_id();
     const int64_t p0 = blk * MSB;
     const int cnt = (int)((n - p0) < MSB ? (n - p0) : MSB);
@@ -598,6 +599,7 @@ __device__ __forceinline__ uint32_t ms_block_exact(const float* __restrict__ xyz
         if (ef == 255u && (sb & 0x7FFFFFu)) break;                 // NaN is absorbing
         const bool s_norm = ef >= 1u && ef <= 254u;
         int f = 0;                                                 // first segment to add serially
+        if (dbg) ++dbg[0];                                         // passes
         if (s_norm) {
             const bool s_neg = (sb >> 31) != 0;
             const int E = (int)ef - 127;
@@ -647,6 +649,7 @@ __device__ __forceinline__ uint32_t ms_block_exact(const float* __restrict__ xyz
         // add [pos, pos+serial_len) one element at a time (all lanes redundantly, LDS broadcast)
         float s = __uint_as_float(sb);
         const int end = pos + serial_len < cnt ? pos + serial_len : cnt;
+        if (dbg) dbg[1] += end - pos;                              // elements added one by one
         int i = pos;
         for (; i + 16 <= end; i += 16) {                            // 16 LDS reads in flight per chain step
             float a[16];
@@ -816,7 +819,7 @@ __device__ __forceinline__ int ms_certify(int cls, const MsEntry& e, bool valid,
 __device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ xyz, int64_t n, int c,
                                                      const MsTables& T, int64_t first, int count,
                                                      uint32_t sb, float* stage, int& n_exact, int& serial_len,
-                                                     int& n_miss) {
+                                                     int& n_miss, int* dbg) {
     const int l = lane_id();
     int done = 0;                                       // children already added
     while (done < count) {
@@ -854,7 +857,8 @@ __device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ x
                 const int jf = __builtin_amdgcn_readlane(j, f);
                 if (jf >= 0 && jf < MS_CAND && !((mk >> jf) & 1u)) ++n_miss;
             }
-            const uint32_t nsb = ms_block_exact(xyz, n, c, first + f, sb, stage, serial_len);
+            const uint32_t nsb = ms_block_exact(xyz, n, c, first + f, sb, stage, serial_len, dbg);
+            if (dbg) ++dbg[2];                                     // exact calls
             const bool same = ((nsb ^ sb) & 0xFF800000u) == 0 && s_norm;   // same sign and binade
             sb = nsb;
             start = f + 1;
@@ -879,6 +883,7 @@ __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, i
     uint32_t sb = sum_in ? __float_as_uint(sum_in[c]) : 0u;      // bits of the running sum (+0.0 at the start)
     int64_t b = 0;                                     // next level-2 row
     int n_exact = 0, n_batches = 0, n_desc = 0, n_miss = 0;
+    int dbg[3] = {0, 0, 0};                            // passes / serially added elements / calls of the exact path
     int serial_len = MS_SEG;
     while (b < T.nb2) {
         ++n_batches;
@@ -911,7 +916,7 @@ __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, i
             ++n_desc;
             const int64_t first = (b + f) * 64;
             const int count = (int)((T.nb - first) < 64 ? (T.nb - first) : 64);
-            const uint32_t nsb = ms_walk_children(xyz, n, c, T, first, count, sb, stage, n_exact, serial_len, n_miss);
+            const uint32_t nsb = ms_walk_children(xyz, n, c, T, first, count, sb, stage, n_exact, serial_len, n_miss, dbg);
             const bool same = ((nsb ^ sb) & 0xFF800000u) == 0 && s_norm;
             sb = nsb;
             start = f + 1;
@@ -926,6 +931,7 @@ __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, i
         if (stats) {
             stats[4 * c + 0] = n_batches; stats[4 * c + 1] = n_miss;     // n_miss: exact blocks the window caused
             stats[4 * c + 2] = n_exact; stats[4 * c + 3] = n_desc;
+            stats[16 + 4 * c + 0] = dbg[0]; stats[16 + 4 * c + 1] = dbg[1]; stats[16 + 4 * c + 2] = dbg[2];
         }
     }
 }
@@ -962,7 +968,7 @@ __global__ __launch_bounds__(256) void mean_seq_k(const float* __restrict__ xyz,
 void ms_plan(Arena& a, int64_t n, MsWs& w) {
     const int64_t nb = ceil_div(n > 0 ? n : 1, MSB);
     const int64_t nb2 = ceil_div(nb, 64);
-    w.stats = a.take<int>(16);
+    w.stats = a.take<int>(32);               // [3][4] walk statistics, [16 + 4 c ..] exact-path counters
     w.pred = a.take<MsPred>(3 * nb2);
     w.rec = a.take<MsRec>(3 * nb);
     w.hdr2 = a.take<MsHdr>(3 * nb2);

@@ -20,7 +20,9 @@ for kind, offset in (("corridor", True), ("corridor", False), ("uniform", True))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) * 1e3
     ws = ops._workspace(L.pch_mean_seq_f32_ws_bytes(n), x.device)
-    st = ws[:64].view(torch.int32).cpu().numpy().reshape(4, 4)[:3]
+    raw_st = ws[:128].view(torch.int32).cpu().numpy()
+    st = raw_st[:16].reshape(4, 4)[:3]
+    ex = raw_st[16:28].reshape(3, 4)
     ops.set_profiling(True)
     ops.mean_seq_f32(x)
     torch.cuda.synchronize()
@@ -29,5 +31,6 @@ for kind, offset in (("corridor", True), ("corridor", False), ("uniform", True))
     print(f"{kind}, frame {'offset' if offset else 'local'}: {dt:.2f} ms, mean {out.cpu().numpy()}  kernels {prof}")
     for c, name in enumerate("xyz"):
         print(f"  column {name}: batches {st[c, 0]}, exact blocks {st[c, 2]} (of them {st[c, 1]} because the candidate "
-              f"window missed), descents {st[c, 3]}")
+              f"window missed), descents {st[c, 3]}; exact path: {ex[c, 2]} calls, {ex[c, 0]} passes, "
+              f"{ex[c, 1]} elements added one by one")
     del x
