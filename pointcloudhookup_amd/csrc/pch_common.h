@@ -203,6 +203,25 @@ __device__ __forceinline__ T wave_scan_incl(T v) {
     for (int o = 1; o < 64; o <<= 1) { T w = __shfl_up(v, o, 64); if (l >= o) v += w; }
     return v;
 }
+// Rank of this lane among the VALID lanes of its wave that hold the same BITS-bit digit (lower lanes first), and the
+// number of such lanes: the stable in-wave ranking of every LSD / MSD pass.  What is accumulated is the set of lanes
+// that DIFFER from this one in some bit: per bit one sign-extended bit field B (0 / -1), one ballot m, and (m ^ B)
+// or-ed into each 32-bit half - five vector instructions per bit (the `bit ? m : ~m` form compiles to nine or ten).
+template <int BITS>
+__device__ __forceinline__ uint32_t wave_match(uint32_t d, bool valid, uint32_t& peers_out) {
+    uint32_t nlo = 0, nhi = 0;
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+        const int32_t B = ((int32_t)(d << (31 - b))) >> 31;
+        const uint64_t m = __ballot(B != 0);
+        nlo |= (uint32_t)m ^ (uint32_t)B;
+        nhi |= (uint32_t)(m >> 32) ^ (uint32_t)B;
+    }
+    const uint64_t v = __ballot(valid);
+    const uint32_t plo = (uint32_t)v & ~nlo, phi = (uint32_t)(v >> 32) & ~nhi;
+    peers_out = (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
+    return __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+}
 #endif  // __HIPCC__
 
 }  // namespace pch

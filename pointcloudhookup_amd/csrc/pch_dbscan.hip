@@ -359,8 +359,11 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
 #ifdef PCH_CS_STAMPS                                    // phase timing of one workgroup (tuning builds only)
     int stamp_i = 0;
 #define CS_STAMP() if (stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) stamps[stamp_i++] = wall_clock64();
+    unsigned long long tacc[3] = {0, 0, 0}, tlast = 0;       // inside the tile loop: rank | offsets | scatter
+#define CS_TILE_STAMP(k) do { const unsigned long long _t = wall_clock64(); tacc[k] += _t - tlast; tlast = _t; } while (0)
 #else
 #define CS_STAMP()
+#define CS_TILE_STAMP(k)
 #endif
     CS_STAMP();
     __shared__ uint32_t hist[CS_PASSES][CS_HREP][CS_BINS];   // replicated: lanes of a wave that share a bin (most do: a
@@ -413,6 +416,7 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
         }
     }
     __syncthreads();
+    CS_STAMP();
     // widths of the relative key; rows outside the grid (the call fails for them) land on arbitrary digits
     const uint32_t ox = cbox[0], oy = cbox[1], oz = cbox[2];
     const bool any = cbox[3] >= ox && cbox[4] >= oy && cbox[5] >= oz;
@@ -466,10 +470,14 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
         }
         return;
     }
-    const uint64_t lt = lanemask_lt();
-    for (int p = 0; p < passes; ++p) {
+    // One pass, unswitched on what the compiler has to know statically: FIRST (the source rows are 12-byte input
+    // rows), LAST (the full keys are written too) and, per tile, FULL (every lane holds a row).  In a full tile the
+    // scattered stores are unconditional, so their number is a constant - and with it the wait for the NEXT tile's
+    // rows, which are requested before them: the memory counter is one in-order queue of loads and stores, and a wait
+    // that cannot count the stores behind a load drains them all (that drain, once per tile, was 40 % of the kernel).
+    auto run_pass = [&](int p, auto FIRST_T, auto LAST_T) {
+        constexpr bool FIRST = decltype(FIRST_T)::value, LAST = decltype(LAST_T)::value;
         const int shift = p * dbits;
-        const bool last = p == passes - 1;
         // pass p writes the sorted-rows array when an even number of passes follows, else the spare one
         const float4* __restrict__ src = ((passes - p) & 1) ? xbuf + lo : pts + lo;     // what pass p-1 wrote
         float4* __restrict__ dst = ((passes - 1 - p) & 1) ? xbuf + lo : pts + lo;
@@ -495,7 +503,7 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
             for (int r = 0; r < CS_ROUNDS; ++r) {
                 const int i = seg + r * 64 + l;
                 const int j = i < cn ? i : 0;
-                if (p == 0) {
+                if constexpr (FIRST) {
                     const Row3 q = rows[j];
                     out[r].x = q.x; out[r].y = q.y; out[r].z = q.z;
                     out[r].w = __uint_as_float((uint32_t)(lo + j));
@@ -505,35 +513,33 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
             }
         };
         float4 nxt[CS_ROUNDS];
-        fetch(0, nxt);
-        for (int t0 = 0; t0 < cn; t0 += CS_TILE) {
+        auto tile = [&](int t0, auto FULL_T) {
+            constexpr bool FULL = decltype(FULL_T)::value;
             float4 row[CS_ROUNDS];
             uint32_t key[CS_ROUNDS], rank[CS_ROUNDS];
             const int seg = t0 + w * (64 * CS_ROUNDS);
 #pragma unroll
             for (int r = 0; r < CS_ROUNDS; ++r) row[r] = nxt[r];
             if (t0 + CS_TILE < cn) fetch(t0 + CS_TILE, nxt);        // in flight while this tile is ranked
+#ifdef PCH_CS_STAMPS
+            tlast = wall_clock64();
+#endif
 #pragma unroll
             for (int r = 0; r < CS_ROUNDS; ++r) {
-                const bool valid = seg + r * 64 + l < cn;
+                const bool valid = FULL || seg + r * 64 + l < cn;
                 bool ok;
                 key[r] = cs_cell_key(g, row[r].x, row[r].y, row[r].z, ok);
                 const uint32_t d = (relkey(key[r]) >> shift) & mask;
-                uint64_t peers = __ballot(valid);
-#pragma unroll
-                for (int b = 0; b < 9; ++b) {
-                    const bool bit = (d >> b) & 1u;
-                    const uint64_t m = __ballot(bit);
-                    peers &= bit ? m : ~m;
-                }
+                uint32_t np;
+                const uint32_t rk = dbits <= 8 ? wave_match<8>(d, valid, np) : wave_match<9>(d, valid, np);
                 const uint32_t prior = cnt[w][d];
-                const uint32_t rk = (uint32_t)__popcll(peers & lt);
                 __builtin_amdgcn_wave_barrier();
-                if (valid && rk == 0) cnt[w][d] = prior + (uint32_t)__popcll(peers);
+                if (valid && rk == 0) cnt[w][d] = prior + np;
                 __builtin_amdgcn_wave_barrier();
                 rank[r] = prior + rk;
             }
             __syncthreads();
+            CS_TILE_STAMP(0);
             if (tid < CS_BINS) {                        // digit tid: waves in order, counters cleared for the next tile
                 uint32_t run = base[tid];
 #pragma unroll
@@ -546,20 +552,33 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
                 base[tid] = run;
             }
             __syncthreads();
+            CS_TILE_STAMP(1);
 #pragma unroll
             for (int r = 0; r < CS_ROUNDS; ++r) {
-                if (seg + r * 64 + l < cn) {
+                if (FULL || seg + r * 64 + l < cn) {
                     const uint32_t d = (relkey(key[r]) >> shift) & mask;
                     const uint32_t pos = off[w][d] + rank[r];
                     dst[pos] = row[r];
-                    if (last) keys_out[lo + pos] = hi | key[r];
+                    if constexpr (LAST) keys_out[lo + pos] = hi | key[r];
                 }
             }
             // off[] is rewritten only behind the next tile's first barrier, which every wave reaches
             // after these reads
-        }
+            CS_TILE_STAMP(2);
+        };
+        fetch(0, nxt);
+        int t0 = 0;
+        for (; t0 + CS_TILE <= cn; t0 += CS_TILE) tile(t0, std::true_type{});
+        if (t0 < cn) tile(t0, std::false_type{});
         __syncthreads();                                // this pass' stores are visible to the whole workgroup
         CS_STAMP();
+    };
+    for (int p = 0; p < passes; ++p) {
+        const bool first = p == 0, last = p == passes - 1;
+        if (first && last) run_pass(p, std::true_type{}, std::true_type{});
+        else if (first)    run_pass(p, std::true_type{}, std::false_type{});
+        else if (last)     run_pass(p, std::false_type{}, std::true_type{});
+        else               run_pass(p, std::false_type{}, std::false_type{});
     }
     // ---- cell heads
     for (int i0 = tid; i0 < cn; i0 += HU * CS_THREADS) {
@@ -580,6 +599,7 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
 #ifdef PCH_CS_STAMPS
     __syncthreads();
     CS_STAMP();
+    if (stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) for (int k = 0; k < 3; ++k) stamps[8 + k] = tacc[k];
 #endif
 }
 
@@ -1945,10 +1965,13 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
                    w.chunk_bad, w.xbuf, w.pts, w.k1, w.head, w.meta + 6, (unsigned long long*)w.cell_box);
 #ifdef PCH_CS_STAMPS
         {
-            unsigned long long t[8];
+            unsigned long long t[11];                    // start | sweep B | sweep H | one per pass | heads
+            PCH_HIP_TRY(hipStreamSynchronize(s));
             PCH_HIP_TRY(hipMemcpy(t, w.cell_box, sizeof(t), hipMemcpyDeviceToHost));
-            for (int q = 1; q <= 5; ++q)
-                fprintf(stderr, "chunksort phase %d: %.2f us\n", q, (double)(t[q] - t[q - 1]) / 100.0);
+            for (int q = 1; q <= 6; ++q)
+                fprintf(stderr, "chunksort phase %d: %.2f us\n", q, (double)(long long)(t[q] - t[q - 1]) / 100.0);
+            fprintf(stderr, "chunksort tiles: rank %.2f us, offsets %.2f us, scatter %.2f us\n", (double)t[8] / 100.0,
+                    (double)t[9] / 100.0, (double)t[10] / 100.0);
         }
 #endif
         ks = w.k1;

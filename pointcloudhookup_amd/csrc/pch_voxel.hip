@@ -171,21 +171,6 @@ __device__ __forceinline__ uint64_t vx_key(const VoxelPlan& g, const double* __r
     return (((ix << g.by) | iy) << g.bz) | iz;
 }
 
-// rank of this lane among the lanes of its wave that hold the same `bits`-bit digit (valid lanes only),
-// and the number of such lanes
-template <int BITS>
-__device__ __forceinline__ uint32_t vx_match(uint32_t d, bool valid, uint32_t& peers_out) {
-    uint64_t peers = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < BITS; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t m = __ballot(bit);
-        peers &= bit ? m : ~m;
-    }
-    peers_out = (uint32_t)__popcll(peers);
-    return (uint32_t)__popcll(peers & lanemask_lt());
-}
-
 // ---- level 1a: digit histogram of every tile ------------------------------------------------
 __global__ __launch_bounds__(VP_THREADS) void vx_tilehist_k(const double* __restrict__ xyz, VoxelPlan g,
                                                             const double* __restrict__ minb,
@@ -422,7 +407,7 @@ __global__ __launch_bounds__(VP_THREADS) void vx_scatter_k(const double* __restr
         const bool valid = seg + r * 64 + l < cend;
         dig[r] = (uint32_t)(vx_key(g, mb, q[r]) >> g.rem);
         uint32_t np;
-        const uint32_t rk = vx_match<VP_MAXBITS>(dig[r], valid, np);
+        const uint32_t rk = wave_match<VP_MAXBITS>(dig[r], valid, np);
         const uint32_t prior = cnt[w][dig[r]];
         __builtin_amdgcn_wave_barrier();
         if (valid && rk == 0) cnt[w][dig[r]] = prior + np;
@@ -671,7 +656,7 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
                         pp[r] = valid ? sh.perm[cur][i] : (uint16_t)0;
                         const uint32_t d = (kk[r] >> shift) & 255u;
                         uint32_t np;
-                        const uint32_t rk = vx_match<8>(d, valid, np);
+                        const uint32_t rk = wave_match<8>(d, valid, np);
                         const uint32_t prior = sh.cnt[w][d];
                         __builtin_amdgcn_wave_barrier();
                         if (valid && rk == 0) sh.cnt[w][d] = prior + np;
@@ -764,7 +749,7 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
                         const bool valid = segb + r * 64 + l < R;
                         dig[r] = (uint32_t)((vx_key(g, mb, q[r]) & remmask) >> (8 * p)) & 255u;
                         uint32_t npeer;
-                        const uint32_t rk = vx_match<8>(dig[r], valid, npeer);
+                        const uint32_t rk = wave_match<8>(dig[r], valid, npeer);
                         const uint32_t prior = sh.cnt[w][dig[r]];
                         __builtin_amdgcn_wave_barrier();
                         if (valid && rk == 0) sh.cnt[w][dig[r]] = prior + npeer;
