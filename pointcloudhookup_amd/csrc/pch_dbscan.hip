@@ -304,12 +304,11 @@ __global__ __launch_bounds__(DB_THREADS) void db_add_offset_k(int32_t* __restric
     if (i < n && labels[i] >= 0) labels[i] += off;
 }
 
-// sorted order: gather coordinates (+ original row in .w) and flag cell heads
+// sorted order: gather coordinates (+ original row in .w)
 __global__ __launch_bounds__(DB_THREADS) void db_gather_k(const float* __restrict__ xyz,
                                                           const uint64_t* __restrict__ keys,
                                                           const uint32_t* __restrict__ vals, int64_t n,
-                                                          float4* __restrict__ pts,
-                                                          uint32_t* __restrict__ head) {
+                                                          float4* __restrict__ pts) {
     const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
     if (i >= n) return;
     const uint32_t o = vals[i];
@@ -319,7 +318,6 @@ __global__ __launch_bounds__(DB_THREADS) void db_gather_k(const float* __restric
     p.z = xyz[3 * (int64_t)o + 2];
     p.w = __uint_as_float(o);
     pts[i] = p;
-    head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
 }
 
 // ---- chunk-local sort: keys + sort + gather for one chunk per workgroup --------------------
@@ -332,7 +330,7 @@ __global__ __launch_bounds__(DB_THREADS) void db_gather_k(const float* __restric
 // sorted is the key RELATIVE to it - same order, but as many bits as the chunk's extent needs (15-17 for a
 // 50 000-row chunk) instead of the tile's (21+), i.e. two 8/9-bit passes instead of three.  Sweep H builds
 // the digit histograms of every pass; pass 0 reads the input rows, the last pass writes the sorted rows and
-// their full keys; a final sweep flags the cell heads.  Replaces db_chunkbad, db_keys, every radix pass (histogram + 3 scan
+// their full keys (the cell heads are read off those keys by db_heads_k / db_cells_k).  Replaces db_chunkbad, db_keys, every radix pass (histogram + 3 scan
 // kernels + scatter) and db_gather of the global path.
 struct Row3 { float x, y, z; };               // 4-byte aligned: loads as one global_load_dwordx3
 constexpr int CS_THREADS = 1024;
@@ -355,7 +353,7 @@ __device__ __forceinline__ uint32_t cs_cell_key(const DbGrid& g, float x, float 
 __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
     const float* __restrict__ xyz, int64_t n, DbGrid g, uint32_t* __restrict__ bad,
     float4* __restrict__ xbuf, float4* __restrict__ pts, uint64_t* __restrict__ keys_out,
-    uint32_t* __restrict__ head, uint32_t* __restrict__ status, unsigned long long* __restrict__ stamps) {
+    uint32_t* __restrict__ status, unsigned long long* __restrict__ stamps) {
 #ifdef PCH_CS_STAMPS                                    // phase timing of one workgroup (tuning builds only)
     int stamp_i = 0;
 #define CS_STAMP() if (stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) stamps[stamp_i++] = wall_clock64();
@@ -466,7 +464,6 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
             pts[lo + i] = o4;
             bool ok;
             keys_out[lo + i] = isbad ? hi : (hi | cs_cell_key(g, q.x, q.y, q.z, ok));
-            head[lo + i] = i == 0 ? 1u : 0u;
         }
         return;
     }
@@ -580,22 +577,6 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
         else if (last)     run_pass(p, std::false_type{}, std::true_type{});
         else               run_pass(p, std::false_type{}, std::false_type{});
     }
-    // ---- cell heads
-    for (int i0 = tid; i0 < cn; i0 += HU * CS_THREADS) {
-        uint64_t ka[HU], kb[HU];
-#pragma unroll
-        for (int u = 0; u < HU; ++u) {
-            const int i = i0 + u * CS_THREADS;
-            const int j = i < cn ? i : i0;
-            ka[u] = keys_out[lo + j];
-            kb[u] = j > 0 ? keys_out[lo + j - 1] : ~ka[u];
-        }
-#pragma unroll
-        for (int u = 0; u < HU; ++u) {
-            const int i = i0 + u * CS_THREADS;
-            if (i < cn) head[lo + i] = ka[u] != kb[u] ? 1u : 0u;
-        }
-    }
 #ifdef PCH_CS_STAMPS
     __syncthreads();
     CS_STAMP();
@@ -603,30 +584,102 @@ __global__ __launch_bounds__(CS_THREADS) void db_chunksort_k(
 #endif
 }
 
+// ---- cells of the sorted rows.  A row is a cell head when its key differs from the key in front of it; nobody
+// materialises those flags: db_heads_k counts them per SCAN_TILE rows, scan_tile_sums_u32 turns the counts into tile
+// offsets (and the number of cells), and db_cells_k scans its tile again while it writes what depends on the cell
+// index.  (Until round 3 the sort kernels wrote a flag per row, a three-launch scan rewrote it and db_cells_k read
+// it back - and the chunk sort's own flag sweep ran on 196 workgroups.)
+constexpr int DC_ITEMS = SCAN_TILE / DB_THREADS;          // 8 consecutive rows per thread
+static_assert(DC_ITEMS == 8, "two 64-byte key loads per thread");
+
+__device__ __forceinline__ void dc_load_keys(const uint64_t* __restrict__ keys, int64_t base, int64_t n,
+                                             uint64_t (&k)[DC_ITEMS], uint64_t& prev) {
+    if (base + DC_ITEMS <= n) {
+        const ulonglong2* q = reinterpret_cast<const ulonglong2*>(keys + base);     // base is a multiple of 8
+#pragma unroll
+        for (int j = 0; j < DC_ITEMS / 2; ++j) { const ulonglong2 v = q[j]; k[2 * j] = v.x; k[2 * j + 1] = v.y; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < DC_ITEMS; ++j) k[j] = base + j < n ? keys[base + j] : 0ull;
+    }
+    prev = (base > 0 && base < n) ? keys[base - 1] : 0ull;
+}
+
+__global__ __launch_bounds__(DB_THREADS) void db_heads_k(const uint64_t* __restrict__ keys, int64_t n,
+                                                         uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t wsum[DB_WAVES];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * DC_ITEMS;
+    uint64_t k[DC_ITEMS], prev;
+    dc_load_keys(keys, base, n, k, prev);
+    uint32_t heads = 0;
+#pragma unroll
+    for (int j = 0; j < DC_ITEMS; ++j) {
+        const int64_t i = base + j;
+        heads += (i < n && (i == 0 || k[j] != (j ? k[j - 1] : prev))) ? 1u : 0u;
+    }
+    heads = wave_reduce_add(heads);
+    if (lane_id() == 0) wsum[wave_id()] = heads;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < DB_WAVES; ++w) t += wsum[w];
+        tile_sums[blockIdx.x] = t;
+    }
+}
+
 __global__ __launch_bounds__(DB_THREADS) void db_cells_k(const uint64_t* __restrict__ keys,
-                                                         const uint32_t* __restrict__ excl, int64_t n,
+                                                         const uint32_t* __restrict__ tile_excl, int64_t n,
                                                          int sh, int64_t nchunks,
                                                          uint32_t* __restrict__ cid,
                                                          uint32_t* __restrict__ cell_start,
                                                          uint64_t* __restrict__ cell_key,
                                                          uint32_t* __restrict__ chunk_cells,
                                                          uint32_t* __restrict__ cell_acc) {
-    const int64_t i = (int64_t)blockIdx.x * DB_THREADS + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t key = keys[i], prev = i ? keys[i - 1] : 0;
-    const bool head = (i == 0 || key != prev);
-    const uint32_t c = excl[i] + (head ? 1u : 0u) - 1u;
-    cid[i] = c;
-    if (head) {
-        cell_start[c] = (uint32_t)i;
-        cell_key[c] = key;
-        uint4* a4 = reinterpret_cast<uint4*>(cell_acc + 8 * (int64_t)c);     // neutral start of db_cellstats_k
-        a4[0] = make_uint4(0u, 0u, 0u, 0u);
-        a4[1] = make_uint4(0u, 0u, 0u, 0u);
-        const uint64_t ch = sh < 64 ? key >> sh : 0, pch = sh < 64 ? prev >> sh : 0;
-        if (i == 0 || ch != pch) chunk_cells[ch] = c;      // every chunk holds rows, hence cells
+    __shared__ uint32_t wsum[DB_WAVES];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * DC_ITEMS;
+    uint64_t k[DC_ITEMS], prev;
+    dc_load_keys(keys, base, n, k, prev);
+    bool hd[DC_ITEMS];
+    uint32_t heads = 0;
+#pragma unroll
+    for (int j = 0; j < DC_ITEMS; ++j) {
+        const int64_t i = base + j;
+        hd[j] = i < n && (i == 0 || k[j] != (j ? k[j - 1] : prev));
+        heads += hd[j] ? 1u : 0u;
     }
-    if (i == n - 1) { cell_start[c + 1] = (uint32_t)n; chunk_cells[nchunks] = c + 1; }
+    const uint32_t incl = wave_scan_incl(heads);
+    if (lane_id() == 63) wsum[wave_id()] = incl;
+    __syncthreads();
+    uint32_t c = tile_excl[blockIdx.x] + incl - heads;           // heads in front of this thread's first row
+    for (int w = 0; w < wave_id(); ++w) c += wsum[w];
+    uint32_t cc[DC_ITEMS];
+#pragma unroll
+    for (int j = 0; j < DC_ITEMS; ++j) {
+        const int64_t i = base + j;
+        c += hd[j] ? 1u : 0u;
+        cc[j] = c - 1u;                                          // cell of row i (row 0 is a head, so c >= 1)
+        if (hd[j]) {
+            const uint64_t key = k[j], pk = j ? k[j - 1] : prev;
+            cell_start[cc[j]] = (uint32_t)i;
+            cell_key[cc[j]] = key;
+            uint4* a4 = reinterpret_cast<uint4*>(cell_acc + 8 * (int64_t)cc[j]);   // neutral start of db_cellstats_k
+            a4[0] = make_uint4(0u, 0u, 0u, 0u);
+            a4[1] = make_uint4(0u, 0u, 0u, 0u);
+            const uint64_t ch = sh < 64 ? key >> sh : 0, pch = sh < 64 ? pk >> sh : 0;
+            if (i == 0 || ch != pch) chunk_cells[ch] = cc[j];    // every chunk holds rows, hence cells
+        }
+        if (i == n - 1) { cell_start[cc[j] + 1] = (uint32_t)n; chunk_cells[nchunks] = cc[j] + 1; }
+    }
+    if (base + DC_ITEMS <= n) {
+        uint4* o = reinterpret_cast<uint4*>(cid + base);
+        o[0] = make_uint4(cc[0], cc[1], cc[2], cc[3]);
+        o[1] = make_uint4(cc[4], cc[5], cc[6], cc[7]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < DC_ITEMS; ++j)
+            if (base + j < n) cid[base + j] = cc[j];
+    }
 }
 // ---- neighbour rows of one cell: lanes 0..24 each binary-search one (dy,dz) row ---------
 struct RowSet {
@@ -1689,14 +1742,14 @@ struct DbWs {
     uint32_t* comp;          // [n][3] compressed cell coordinates (fallback for grids beyond the 64-bit key)
     uint32_t* flag2;         // [n + 8] head flags kept beside their scan
     unsigned long long* core_stats;   // [4] tallies of db_core_k<true> (pch_dbscan_set_pair_counting)
-    uint32_t *scan1_a, *scan1_b;      // zeroed words of the single-pass scans (cell ids; cluster ranks)
+    uint32_t* scan1_b;                // zeroed words of the single-pass scan of the cluster ranks
 };
 
 static void db_plan(Arena& a, int64_t n, DbWs& w) {
     const int64_t nn = n > 0 ? n : 1;
     w.meta = a.take<uint32_t>(64);                       // exactly one 256-byte arena block ...
-    w.scan1_a = a.take<uint32_t>(scan1_ws_u32(nn));      // ... directly followed by the zero-initialised words of the
-    w.scan1_b = a.take<uint32_t>(scan1_ws_u32(nn / 32 + 1));   // two single-pass scans and by the per-chunk table:
+    w.scan1_b = a.take<uint32_t>(scan1_ws_u32(nn / 32 + 1));   // ... directly followed by the zero-initialised words
+                                                         // of the single-pass scan and by the per-chunk table:
     w.chunk_cells = a.take<uint32_t>(nn + 8);            // ONE fill clears them all (db_plan keeps them adjacent)
     w.core_stats = a.take<unsigned long long>(4);
     w.chunk_bad = a.take<uint32_t>(nn + 8);              // one word per chunk (chunk_size >= 1)
@@ -1958,11 +2011,11 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
         const bool in1 = radix_sort_result_buffer(nbits) == 1;
         ks = in1 ? w.k1 : w.k0;
         const uint32_t* vs = in1 ? w.v1 : w.v0;
-        PCH_LAUNCH("db_gather", db_gather_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, ks, vs, n, w.pts, w.head);
+        PCH_LAUNCH("db_gather", db_gather_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, ks, vs, n, w.pts);
     } else if (cellbits <= 32 && chunk_size <= CS_MAX_CHUNK && !force_global && (force_chunk || nchunks >= CS_MIN_CHUNKS)) {
         // chunk-local path: one workgroup per chunk builds keys, sorts and gathers
         PCH_LAUNCH("db_chunksort", db_chunksort_k, dim3((unsigned)nchunks), dim3(CS_THREADS), 0, s, xyz, n, g,
-                   w.chunk_bad, w.xbuf, w.pts, w.k1, w.head, w.meta + 6, (unsigned long long*)w.cell_box);
+                   w.chunk_bad, w.xbuf, w.pts, w.k1, w.meta + 6, (unsigned long long*)w.cell_box);
 #ifdef PCH_CS_STAMPS
         {
             unsigned long long t[11];                    // start | sweep B | sweep H | one per pass | heads
@@ -1985,23 +2038,20 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
         const bool in1 = radix_sort_result_buffer(nbits) == 1;
         ks = in1 ? w.k1 : w.k0;
         const uint32_t* vs = in1 ? w.v1 : w.v0;
-        PCH_LAUNCH("db_gather", db_gather_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, ks, vs, n, w.pts, w.head);
+        PCH_LAUNCH("db_gather", db_gather_k, dim3(gn), dim3(DB_THREADS), 0, s, xyz, ks, vs, n, w.pts);
     }
-    if (scan1_pays(n)) PCH_TRY(scan1_exclusive_u32(w.head, w.head, n, w.scan1_a, w.meta + 7, s));
-    else PCH_TRY(scan_exclusive_u32(w.head, w.head, n, w.scan_ws, w.meta + 7, s));
+    const int64_t ntile = ceil_div(n, (int64_t)SCAN_TILE);
+    PCH_LAUNCH("db_heads", db_heads_k, dim3((unsigned)ntile), dim3(DB_THREADS), 0, s, ks, n, w.scan_ws);
+    PCH_TRY(scan_tile_sums_u32(w.scan_ws, ntile, w.meta + 7, s));
     // the cell count sizes the next grids: fetch it while db_cells_k (sized by n) runs
     uint32_t st_m[2];
     PCH_TRY(peek_enqueue(w.meta + 6, sizeof(st_m), s));
-    PCH_LAUNCH("db_cells", db_cells_k, dim3(gn), dim3(DB_THREADS), 0, s, ks, (const uint32_t*)w.head, n,
+    PCH_LAUNCH("db_cells", db_cells_k, dim3((unsigned)ntile), dim3(DB_THREADS), 0, s, ks, (const uint32_t*)w.scan_ws, n,
                cellbits, nchunks, w.cid, w.cell_start, w.cell_key, w.chunk_cells, w.cell_acc);
     PCH_TRY(peek_wait(st_m, sizeof(st_m)));
     if (st_m[0] != 0) {
         set_error("finite coordinates outside the supplied bounding box");
         return PCH_ERR_ARG;
-    }
-    if (st_m[1] == 0xFFFFFFFFu) {                       // the single-pass scan's bounded wait gave up (pch_prims.h)
-        set_error("stage C: a device-side look-back wait ran out of its budget; outputs are undefined");
-        return PCH_ERR_TIMEOUT;
     }
     const int m = (int)st_m[1];
     const unsigned gc = (unsigned)ceil_div(m, DB_WAVES);

@@ -13,6 +13,11 @@ int scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* w
 int scan_exclusive_popc_u32(const uint32_t* bits, uint32_t* out, int64_t n, uint32_t* ws,
                             uint32_t* total, hipStream_t s);
 
+// ---- the middle step alone, for callers whose own kernels do the tile sums and the tile scans (SCAN_TILE elements
+// per workgroup): in-place exclusive scan of nb tile sums (one workgroup), grand total to `total` (optional, device)
+constexpr int SCAN_TILE = 2048;
+int scan_tile_sums_u32(uint32_t* tile_sums, int64_t nb, uint32_t* total, hipStream_t s);
+
 // ---- the same in ONE launch (decoupled look-back).  zeroed_ws: scan1_ws_u32(n) uint32 words, 8-byte aligned, that
 // are ZERO when the kernel starts (the caller folds that into a fill or a kernel it runs anyway); `total`
 // (optional, device) must be ZERO too and receives the grand total - or 0xFFFFFFFF if a tile's bounded wait gave

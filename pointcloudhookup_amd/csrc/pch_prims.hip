@@ -11,6 +11,7 @@ namespace pch {
 constexpr int SC_THREADS = 256;
 constexpr int SC_ITEMS   = 8;
 constexpr int SC_TILE    = SC_THREADS * SC_ITEMS;   // 2048 elements per workgroup
+static_assert(SC_TILE == SCAN_TILE, "pch_prims.h");
 
 // POPC: the scanned values are the population counts of the input words (row bitmap -> ranks), taken on load
 template <bool POPC>
@@ -214,6 +215,11 @@ static int scan_launch(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* w
 int scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* ws,
                        uint32_t* total, hipStream_t s) {
     return scan_launch<false>(in, out, n, ws, total, s);
+}
+
+int scan_tile_sums_u32(uint32_t* tile_sums, int64_t nb, uint32_t* total, hipStream_t s) {
+    PCH_LAUNCH("scan_bsums", scan_bsums_k, dim3(1), dim3(1024), 0, s, tile_sums, nb, total);
+    return PCH_OK;
 }
 
 int scan_exclusive_popc_u32(const uint32_t* bits, uint32_t* out, int64_t n, uint32_t* ws,
