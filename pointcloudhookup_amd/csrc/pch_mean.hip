@@ -36,7 +36,7 @@ constexpr int MS_FIX_MAX  = 8;      // ... holding at most this many tie element
 // mask: candidates j whose S / fix entries were computed (bit j); a candidate outside the mask is "unknown" to the walk
 struct MsHdr { int emax; uint32_t tie; uint32_t flags; uint32_t mask; };
 constexpr uint32_t MS_ALLCAND = (1u << MS_CAND) - 1u;
-constexpr int MS_WIN = 4;           // predicted window: candidates jp-1 .. jp+2 (+ candidate 0, always computed)
+constexpr int MS_WIN = 4;           // predicted window: candidates jp-1 .. jp+2
 
 // level-1 record of one (column, block): three 128-byte lines, assembled in LDS and written by one
 // store instruction (whole lines: no read-modify-write in HBM), read by the lane that owns the
@@ -103,7 +103,7 @@ __device__ __forceinline__ uint32_t ms_tie_bit(float x) {
 // binade follows from the prefix of the column, which a block cannot know - but it can be ESTIMATED cheaply: one
 // sampled row per block gives the sum of every 65 536-point row (ms_sample_k), a prefix over the rows (ms_prefix_k)
 // the running sum in front of every row, and the float32 sum stops growing roughly 25 binades above the typical
-// element (increments round to zero).  ms_summary_k then computes candidate 0 and a window of MS_WIN candidates around
+// element (increments round to zero).  ms_summary_k then computes a window of MS_WIN candidates around
 // the estimate instead of all 24 (2.4x fewer vector instructions: the kernel is bound by them).  A wrong estimate
 // costs time, never exactness: a candidate that was not computed is "unknown" to the walk, which then adds the
 // block element by element (ms_block_exact).  Blocks with both signs, non-finite values or a prefix dominated by
@@ -356,15 +356,20 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         int S[MS_CAND];
 #pragma unroll
         for (int j = 0; j < MS_CAND; ++j) S[j] = 0;
-        int W[1 + MS_WIN] = {0, 0, 0, 0, 0};                   // the sums of the windowed path (see below)
+        int W[MS_WIN] = {0, 0, 0, 0};                          // the sums of the windowed path (see below)
         // ---- candidate window (wave-uniform): see the comment above ms_sample_k
         uint32_t cmask = MS_ALLCAND;
         int j0 = 1;                                            // first candidate of the window (>= 1)
         if (live && pred) {
-            bool neg = false, pos = false;
+            // both signs present?  (-0.0 counts as negative: such a block merely keeps all candidates)
+            uint32_t orb = 0;
+            float top = 0.0f;
 #pragma unroll
-            for (int i = 0; i < MS_PER; ++i) { neg |= a[i] < 0.0f; pos |= a[i] > 0.0f; }
-            const bool mixed = __ballot(neg) != 0 && __ballot(pos) != 0;
+            for (int i = 0; i < MS_PER; i += 2) {
+                orb = orb | __float_as_uint(a[i]) | __float_as_uint(a[i + 1]);         // v_or3_b32
+                top = fmaxf(top, fmaxf(a[i], a[i + 1]));                               // v_max3_f32 (finite: live)
+            }
+            const bool mixed = __ballot((orb >> 31) != 0u) != 0 && __ballot(top > 0.0f) != 0;
             const MsPred pr = pred[(int64_t)c * nb2 + (blk >> 6)];
             const double start = pr.pre + pr.rowsum * ((double)(blk & 63) * (1.0 / 64.0));
             const double mass = fabs(pr.pre) + fabs(pr.rowsum);
@@ -378,30 +383,40 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
                 jp = jp < 2 ? 2 : jp;                                   // window = jp-1 .. jp+2, inside 1 .. 23
                 jp = jp > MS_CAND - 3 ? MS_CAND - 3 : jp;
                 j0 = jp - 1;
-                cmask = 1u | (((1u << MS_WIN) - 1u) << j0);
+                // candidate 0 (a running sum within a factor two of the block's largest element) is not part of the
+                // window: a same-sign block behind the first one cannot meet it
+                cmask = ((1u << MS_WIN) - 1u) << j0;
             }
         }
         if (live && cmask != MS_ALLCAND) {
             float magic[MS_WIN];
-            uint32_t acc[MS_WIN], acc0 = 0;
+            uint32_t acc[MS_WIN];
 #pragma unroll
             for (int k = 0; k < MS_WIN; ++k) {
                 magic[k] = ldexpf(1.5f, 23 + j0 + k);                   // 1.5 * 2^(23+j), exact
                 acc[k] = 0u - (uint32_t)MS_PER * __float_as_uint(magic[k]);
             }
+            // An element ties at window candidate j iff its lowest set bit is 2^(j-1) >= 2^(j0-1): only a multiple of
+            // 2^(j0-1) can.  That test is one add, one subtract and one compare (the exact bit costs eight
+            // instructions); the exact bits are computed only when some element passes it - for the deep windows of
+            // a long column (j0 ~ 20) that is one block in a thousand.
+            const float mtest = ldexpf(1.5f, 23 + j0 - 1);
+            bool maybe = false;
             float absum = 0.0f;
 #pragma unroll
             for (int i = 0; i < MS_PER; ++i) {
                 const float x = ldexpf(a[i], 22 - emax);       // a / ulp(2^(emax+1)), |x| < 2^23, exact
                 absum += fabsf(x);
-                tie |= ms_tie_bit(x);
-                acc0 += (uint32_t)(int)rintf(x);
+                maybe |= ((x + mtest) - mtest) == x;
 #pragma unroll
                 for (int k = 0; k < MS_WIN; ++k) acc[k] += __float_as_uint(x + magic[k]);
             }
-            W[0] = (int)acc0;                                  // candidate 0, then the window j0 .. j0+3
+            if (__ballot(maybe)) {
 #pragma unroll
-            for (int k = 0; k < MS_WIN; ++k) W[1 + k] = (int)acc[k];
+                for (int i = 0; i < MS_PER; ++i) tie |= ms_tie_bit(ldexpf(a[i], 22 - emax));
+            }
+#pragma unroll
+            for (int k = 0; k < MS_WIN; ++k) W[k] = (int)acc[k];       // the window j0 .. j0+3
             A0 = (int)ceilf(absum * 1.00001f) + 1;
             tie &= cmask;                                      // ties of candidates that were not computed do not matter
         } else if (live) {
@@ -483,15 +498,15 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         }
         MsRec* rec = &stage[wave_id()];
         if (live && cmask != MS_ALLCAND) {
-            // five sums only: each is split into a low 16-bit and a high part per lane (|sum| <= 2^27), so that both
+            // four sums only: each is split into a low 16-bit and a high part per lane (|sum| <= 2^27), so that both
             // wave totals fit 32 bits, and put together again in 64 bits
             if (l < MS_CAND) rec->S[l] = 0;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int k = 0; k < 1 + MS_WIN; ++k) {
+            for (int k = 0; k < MS_WIN; ++k) {
                 const uint32_t lo = ms_wave_all((uint32_t)W[k] & 0xFFFFu, [](uint32_t a, uint32_t b) { return a + b; });
                 const uint32_t hi = ms_wave_all((uint32_t)(W[k] >> 16), [](uint32_t a, uint32_t b) { return a + b; });
-                if (l == 0) rec->S[k == 0 ? 0 : j0 + k - 1] = ((long long)(int)hi << 16) + (long long)lo;
+                if (l == 0) rec->S[j0 + k] = ((long long)(int)hi << 16) + (long long)lo;
             }
         } else {
         // transposed reduction: 24 -> 12 -> 6 -> 3 values per lane while summing over the lane
