@@ -739,7 +739,13 @@ __global__ __launch_bounds__(256) void ms_level2_k(const MsRec* __restrict__ rec
         const int j = j2 + shift;
         long long n0 = 0, n1 = 0, A = 0;
         bool tie = false;
-        if (__ballot(live && j < MS_CAND && !((h.mask >> j) & 1u))) miss2 |= 1u << j2;
+        if (__ballot(live && j < MS_CAND && !((h.mask >> j) & 1u))) {
+            // a child did not compute this candidate (prediction windows): the row's entry is "unknown" to the walk
+            // (ms_classify checks the mask before anything is read), so there is nothing to reduce or to store -
+            // with windowed children that is ~20 of the 24 candidates of a row
+            miss2 |= 1u << j2;
+            continue;
+        }
         if (live && j < MS_CAND) {
             const long long S = rec64(6 + 2 * j);
             const uint32_t f = rec[6 + 2 * MS_CAND + j];
