@@ -18,7 +18,7 @@
 //   ms_walk_k    : one wave per column walks level-2 rows 64 at a time (prefix scan of the
 //                  increments + per-row certificate that no prefix can leave the binade), opens
 //                  the children of a row that fails, and adds a child that fails exactly with all
-//                  64 lanes (ms_block_exact).
+//                  64 lanes (ms_blocks_exact).
 // Order inside a certified block is irrelevant, hence the result equals the sequential sum.
 #include "pch_mean.h"
 
@@ -106,7 +106,7 @@ __device__ __forceinline__ uint32_t ms_tie_bit(float x) {
 // element (increments round to zero).  ms_summary_k then computes a window of MS_WIN candidates around
 // the estimate instead of all 24 (2.4x fewer vector instructions: the kernel is bound by them).  A wrong estimate
 // costs time, never exactness: a candidate that was not computed is "unknown" to the walk, which then adds the
-// block element by element (ms_block_exact).  Blocks with both signs, non-finite values or a prefix dominated by
+// block element by element (ms_blocks_exact).  Blocks with both signs, non-finite values or a prefix dominated by
 // cancellation keep all 24 candidates.
 struct MsPred { double pre, rowsum, meanabs; };          // per (column, level-2 row)
 
@@ -576,109 +576,71 @@ __device__ __forceinline__ void ms_scan_pairs(long long& c0, long long& c1) {
     }
 }
 
-constexpr int MS_SEG = 16;                       // elements per lane in ms_block_exact
+constexpr int MS_SEG = 16;                       // consecutive elements per lane in ms_blocks_exact
 __device__ __forceinline__ int ms_pad(int i) { return i + (i >> 4); }   // LDS bank spreading
 
-// Adds ONE level-1 block to the running sum exactly, using all 64 lanes: lane l owns the 16
-// consecutive elements [pos+16l, pos+16l+16) and summarises them IN ORDER for the current binade
-// and for both parities of its incoming mantissa (a tie a/u = q+1/2 rounds to the even mantissa,
-// so its increment depends on that parity; after one tie both chains are even and coincide).
-// A parity-pair scan gives every lane its incoming mantissa; lanes whose segment provably stays
-// inside the binade are applied at once, the first segment that does not (an element as large as
-// the sum, a binade or sign change, a non-finite value) is added element by element, and the
-// rest of the block is redone at the new binade.
-__device__ __forceinline__ uint32_t ms_block_exact(const float* __restrict__ xyz, int64_t n, int c,
-                                                   int64_t blk, uint32_t sb, float* stage, int& serial_len,
-                                                   int* dbg) {
+// Adds the level-1 blocks [blk, blk + nblk) to the running sum exactly: literally the sequential float32 chain, run
+// out of registers.  Lane l holds the 16 consecutive elements [16 l, 16 l + 16) of a block (staged through LDS so that
+// the global loads stay coalesced); in round r EVERY lane chains its 16 elements onto the (wave-uniform) running sum
+// and lane r's result becomes the running sum of round r + 1 (v_readlane).  64 rounds x 17 dependent instructions
+// ~ 2.3 us per block, whatever the data; the rows of the NEXT block of a run are requested before the chain of this one
+// starts.  (The earlier form - certified parallel passes at the current binade + element-by-element stretches read back
+// from LDS - cost 2.4 us per PASS and 10 ns per serial element: 3-11 us per block.)  Rows beyond the array's end count
+// as -0.0: s + (-0.0) = s for every s, -0.0 included.  NaN and inf propagate as in numpy's own chain.
+// first_decides: stop behind the first block if the sum is still in the binade (and has the sign) it came with - the
+// caller's tables are still valid then; `added` returns the number of blocks that were added.
+__device__ __forceinline__ uint32_t ms_blocks_exact(const float* __restrict__ xyz, int64_t n, int c,
+                                                    int64_t blk, int nblk, uint32_t sb, float* stage, int* dbg,
+                                                    bool first_decides, int& added) {
     const int l = lane_id();
-    const int64_t p0 = blk * MSB;
-    const int cnt = (int)((n - p0) < MSB ? (n - p0) : MSB);
-    {
-        float v[MSB / 64];                               // all 16 loads in flight before the first LDS write
+    float v0[MSB / 64], v1[MSB / 64];                    // coalesced loads of the next two blocks (two chains of time
+                                                         // for every load to arrive)
+    auto fetch = [&](int64_t b, float (&v)[MSB / 64]) {
+        const int64_t p0 = b * MSB;
 #pragma unroll
         for (int k = 0; k < MSB / 64; ++k) {
-            const int i = l + 64 * k;
-            v[k] = i < cnt ? xyz[3 * (p0 + i) + c] : 0.0f;
+            const int64_t i = p0 + l + 64 * k;
+            v[k] = i < n ? xyz[3 * i + c] : -0.0f;
         }
+    };
+    fetch(blk, v0);
+    if (nblk > 1) fetch(blk + 1, v1);
+    float s = __uint_as_float(sb);
+    added = 0;
+    for (int q = 0; q < nblk; ++q) {
 #pragma unroll
-        for (int k = 0; k < MSB / 64; ++k) {
-            const int i = l + 64 * k;
-            if (i < cnt) stage[ms_pad(i)] = v[k];
+        for (int k = 0; k < MSB / 64; ++k) stage[ms_pad(l + 64 * k)] = v0[k];
+        __syncthreads();
+        float a[MS_SEG];
+#pragma unroll
+        for (int k = 0; k < MS_SEG; ++k) a[k] = stage[ms_pad(MS_SEG * l + k)];
+        __syncthreads();                                 // the stage may be overwritten by the next block
+#pragma unroll
+        for (int k = 0; k < MSB / 64; ++k) v0[k] = v1[k];
+        if (q + 2 < nblk) fetch(blk + q + 2, v1);        // in flight during this chain and the next
+        const int64_t left = n - (blk + q) * MSB;
+        const int cnt = (int)(left < MSB ? left : MSB);
+        auto round = [&](int r) {
+            float t = s;
+#pragma unroll
+            for (int k = 0; k < MS_SEG; ++k) t = t + a[k];
+            s = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(t), r));
+        };
+        if (cnt == MSB) {                                // (a constant trip count: the loop bookkeeping of 64 short
+#pragma unroll 8                                         //  rounds is a sixth of the chain otherwise)
+            for (int r = 0; r < MSB / MS_SEG; ++r) round(r);
+        } else {
+            const int rounds = (cnt + MS_SEG - 1) / MS_SEG;
+            for (int r = 0; r < rounds; ++r) round(r);
+        }
+        if (dbg) { dbg[1] += cnt; ++dbg[2]; }            // elements added one by one / blocks
+        ++added;
+        if (q == 0 && first_decides) {
+            const uint32_t ef = (sb >> 23) & 0xFFu;
+            if (((__float_as_uint(s) ^ sb) & 0xFF800000u) == 0 && ef >= 1u && ef <= 254u) break;
         }
     }
-    __syncthreads();
-    int pos = 0;                        // serial_len (kept across calls) grows while the parallel
-                                        // passes make little progress and falls back when they do
-    while (pos < cnt) {
-        const uint32_t ef = (sb >> 23) & 0xFFu;
-        if (ef == 255u && (sb & 0x7FFFFFu)) break;                 // NaN is absorbing
-        const bool s_norm = ef >= 1u && ef <= 254u;
-        int f = 0;                                                 // first segment to add serially
-        if (dbg) ++dbg[0];                                         // passes
-        if (s_norm) {
-            const bool s_neg = (sb >> 31) != 0;
-            const int E = (int)ef - 127;
-            const int base = pos + MS_SEG * l;
-            int run0 = 0, run1 = 0, mn0 = 0, mn1 = 0, mx0 = 0, mx1 = 0, par0 = 0, par1 = 1;
-            bool bad = false;
-#pragma unroll
-            for (int k = 0; k < MS_SEG; ++k) {
-                const int i = base + k;
-                const float a = (i < cnt) ? stage[ms_pad(i)] : 0.0f;
-                const float x = ldexpf(s_neg ? -a : a, 23 - E);     // real increment of the mantissa
-                const float r = rintf(x);
-                bad |= !(fabsf(x) < 8388608.0f);                   // element >= 2^E, inf or NaN
-                int d0 = (int)r, d1 = d0;
-                if (fabsf(x - r) == 0.5f) {                        // tie: pick the even mantissa
-                    const int fl = (int)floorf(x);
-                    d0 = ((par0 + fl) & 1) ? fl + 1 : fl;
-                    d1 = ((par1 + fl) & 1) ? fl + 1 : fl;
-                }
-                run0 += d0; par0 = (par0 + d0) & 1;
-                run1 += d1; par1 = (par1 + d1) & 1;
-                mn0 = run0 < mn0 ? run0 : mn0; mx0 = run0 > mx0 ? run0 : mx0;
-                mn1 = run1 < mn1 ? run1 : mn1; mx1 = run1 > mx1 ? run1 : mx1;
-            }
-            long long c0 = run0, c1 = run1;
-            ms_scan_pairs(c0, c1);
-            const long long m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);
-            const int pc = (int)(m_cur & 1);
-            long long e0 = __shfl_up(c0, 1, 64), e1 = __shfl_up(c1, 1, 64);
-            if (l == 0) { e0 = 0; e1 = 0; }
-            const long long m_in = m_cur + (pc ? e1 : e0);
-            const int pl = (int)(m_in & 1);
-            const long long hi = pl ? mx1 : mx0, lo = pl ? mn1 : mn0;
-            const bool ok = !bad && m_in + hi + 1 < (1ll << 24) && m_in + lo - 1 >= (1ll << 23);
-            const unsigned long long fail = __ballot(base < cnt && !ok);
-            f = fail ? (int)__builtin_ctzll(fail) : 64;
-            if (f > 0) {
-                const long long m1 = m_cur + ms_readlane64(pc ? c1 : c0, f - 1);
-                sb = (sb & 0xFF800000u) | ((uint32_t)m1 & 0x7FFFFFu);
-                pos += MS_SEG * f;
-            }
-            if (!fail) break;                                      // whole remainder applied
-            // little progress (sum comparable to the elements: binade changes every few adds):
-            // lengthen the element-by-element stretch instead of paying a pass per 16 elements
-            serial_len = (f < 4) ? (serial_len < MSB ? serial_len * 4 : MSB) : MS_SEG;
-        }
-        // add [pos, pos+serial_len) one element at a time (all lanes redundantly, LDS broadcast)
-        float s = __uint_as_float(sb);
-        const int end = pos + serial_len < cnt ? pos + serial_len : cnt;
-        if (dbg) dbg[1] += end - pos;                              // elements added one by one
-        int i = pos;
-        for (; i + 16 <= end; i += 16) {                            // 16 LDS reads in flight per chain step
-            float a[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = stage[ms_pad(i + k)];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) s = s + a[k];
-        }
-        for (; i < end; ++i) s = s + stage[ms_pad(i)];
-        sb = __builtin_amdgcn_readfirstlane(__float_as_uint(s));
-        pos = end;
-    }
-    __syncthreads();
-    return sb;
+    return __float_as_uint(s);
 }
 
 // ---- level 2: one row per 64 level-1 blocks (65 536 points).  Bounds are additive; the net
@@ -839,7 +801,7 @@ __device__ __forceinline__ int ms_certify(int cls, const MsEntry& e, bool valid,
 // Adds the level-1 blocks [first, first+count), count <= 64, to the running sum `sb` (bits).
 __device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ xyz, int64_t n, int c,
                                                      const MsTables& T, int64_t first, int count,
-                                                     uint32_t sb, float* stage, int& n_exact, int& serial_len,
+                                                     uint32_t sb, float* stage, int& n_exact, int& streak,
                                                      int& n_miss, int* dbg) {
     const int l = lane_id();
     int done = 0;                                       // children already added
@@ -870,22 +832,33 @@ __device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ x
         long long m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);   // mantissa entering `start`
         for (;;) {
             const int f = ms_certify(cls, en, valid, start, count, s_norm, m_cur, sb);
-            if (f < 0) { done = count; break; }
+            if (f < 0) { if (start < count) streak = 0; done = count; break; }
             // child f cannot be certified from the table at this binade: add it exactly
-            ++n_exact;
+            if (f > start) streak = 0;                  // the tables carried the walk over some children: no hard stretch
             {
                 const uint32_t mk = (uint32_t)__builtin_amdgcn_readlane((int)h.mask, f);
                 const int jf = __builtin_amdgcn_readlane(j, f);
                 if (jf >= 0 && jf < MS_CAND && !((mk >> jf) & 1u)) ++n_miss;
             }
-            const uint32_t nsb = ms_block_exact(xyz, n, c, first + f, sb, stage, serial_len, dbg);
-            if (dbg) ++dbg[2];                                     // exact calls
-            const bool same = ((nsb ^ sb) & 0xFF800000u) == 0 && s_norm;   // same sign and binade
+            // In a stretch where block after block fails (a sum that keeps changing sign or binade: a zero-mean
+            // column) the table read + certificate in front of every block is pure overhead - the chain is exact
+            // whatever the tables say.  So behind a failing block that left the binade, `streak` more blocks are added
+            // without asking; the run doubles while that keeps happening (at most 32) and is forgotten as soon as a
+            // certificate advances.  An ordinary binade crossing never sees it (the run starts at 0).
+            const int extra = streak < count - (f + 1) ? streak : count - (f + 1);
+            int added = 0;
+            const uint32_t nsb = ms_blocks_exact(xyz, n, c, first + f, 1 + extra, sb, stage, dbg, true, added);
+            // (one block that stayed in its binade: the entries the lanes hold are still good for the children behind it)
+            const bool same = added == 1 && ((nsb ^ sb) & 0xFF800000u) == 0 && s_norm;   // same sign and binade
+            n_exact += added;
             sb = nsb;
-            start = f + 1;
+            start = f + added;
             done = start;
             if (same) m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);
-            else break;                                 // re-read the remaining children at the new binade
+            else {
+                streak = streak ? (streak < 16 ? 2 * streak : 32) : 1;
+                break;                                  // re-read the remaining children at the new binade
+            }
         }
     }
     return sb;
@@ -905,7 +878,7 @@ __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, i
     int64_t b = 0;                                     // next level-2 row
     int n_exact = 0, n_batches = 0, n_desc = 0, n_miss = 0;
     int dbg[3] = {0, 0, 0};                            // passes / serially added elements / calls of the exact path
-    int serial_len = MS_SEG;
+    int streak = 0;                                    // blocks added without asking the tables (ms_walk_children)
     while (b < T.nb2) {
         ++n_batches;
         const uint32_t ef = (sb >> 23) & 0xFFu;
@@ -937,7 +910,7 @@ __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, i
             ++n_desc;
             const int64_t first = (b + f) * 64;
             const int count = (int)((T.nb - first) < 64 ? (T.nb - first) : 64);
-            const uint32_t nsb = ms_walk_children(xyz, n, c, T, first, count, sb, stage, n_exact, serial_len, n_miss, dbg);
+            const uint32_t nsb = ms_walk_children(xyz, n, c, T, first, count, sb, stage, n_exact, streak, n_miss, dbg);
             const bool same = ((nsb ^ sb) & 0xFF800000u) == 0 && s_norm;
             sb = nsb;
             start = f + 1;
