@@ -228,6 +228,10 @@ __global__ __launch_bounds__(256) void selx_hist_k(const float* __restrict__ bas
                                                    SelGate gate) {
     const float* base = base_in;
     sel_gate(gate, base, n, stride);
+    // the grid is sized for the column the launch names; on the gated source (the bracket's candidates: ~1 % of it) most
+    // workgroups have no tile - they leave before the pick and the 16 KB of LDS zeroing (workgroup 0 stays: it records
+    // the pick)
+    if (blockIdx.x != 0 && (int64_t)blockIdx.x * SEL_TILE >= n) return;
     constexpr int REP = PASS == 0 ? SEL_REP0 : 1;
     constexpr int NH = PASS == 0 ? 1 : NR;
     __shared__ uint32_t hh[NH][REP][SEL_BINS];
@@ -301,6 +305,7 @@ __global__ __launch_bounds__(256) void selx_next_k(const float* __restrict__ bas
                                                    SelRun* __restrict__ run, uint32_t* __restrict__ hist, SelGate gate) {
     const float* base = base_in;
     sel_gate(gate, base, n, stride);
+    if (blockIdx.x != 0 && (int64_t)blockIdx.x * SEL_TILE >= n) return;      // no tile (see selx_hist_k)
     const SelState st = sel_pick_block<2>(run->st[2], selx_hist_of(hist, 0, 2));
     if (blockIdx.x == 0 && threadIdx.x == 0) run->st[3] = st;
     if (st.need_next == 0) return;
@@ -372,10 +377,22 @@ struct BrState {
     uint32_t pad;
 };
 
-__global__ void sel_sample_k(const float* __restrict__ base, int64_t ns, float* __restrict__ sample) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < ns) sample[i] = base[(i / SEL_GROUP) * SEL_EVERY + (i % SEL_GROUP)];
+// four consecutive values per thread (SEL_GROUP is a multiple of 4, SEL_EVERY of 16: both sides 16-byte aligned when
+// the column is); stride 3 reads the z of (n,3) rows (base = rows + 2)
+__global__ void sel_sample_k(const float* __restrict__ base, int64_t stride, int64_t ns, float* __restrict__ sample) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= ns) return;
+    const int64_t src = (i / SEL_GROUP) * SEL_EVERY + (i % SEL_GROUP);
+    float4 q;
+    if (stride == 1 && (reinterpret_cast<uintptr_t>(base) & 15u) == 0) {
+        q = *reinterpret_cast<const float4*>(base + src);
+    } else {
+        q.x = base[src * stride]; q.y = base[(src + 1) * stride];
+        q.z = base[(src + 2) * stride]; q.w = base[(src + 3) * stride];
+    }
+    *reinterpret_cast<float4*>(sample + i) = q;
 }
+static_assert(SEL_GROUP % 4 == 0 && SEL_EVERY % 4 == 0, "sel_sample_k");
 
 constexpr int SEL_STAGE = 2 * SEL_TILE;                  // candidates a workgroup stages in LDS before it reserves output
 
@@ -542,38 +559,62 @@ static int select_rounds(const float* base, int64_t n, int64_t stride, bool with
     return PCH_OK;
 }
 
-// the histogram / next passes (need only the raw values) ...
-static int select_passes(const float* base, int64_t n, int64_t stride, double q_percent, SelWs& w,
-                         hipStream_t s) {
-    const PctIndex pi = pct_index(n, q_percent);
-    const SelGate always = {nullptr, nullptr, nullptr};
-    SelRun* fin = w.run + 2;
-    uint32_t* hfin = w.xhist + 6 * SEL_BINS;
-    if (!(w.sample && stride == 1 && n >= SEL_BRACKET_MIN)) {
-        PCH_LAUNCH("sel_init", selx_init_k, dim3((unsigned)ceil_div(9 * SEL_BINS, 256)), dim3(256), 0, s, w.xhist,
-                   9 * SEL_BINS, w.run, 3, 0ull, 0ull, (unsigned long long)pi.k0, (BrState*)nullptr);
-        return select_rounds(base, n, stride, !pi.same, fin, hfin, s, always, n);
-    }
-    // ---- bracket from the sample: ranks around k0 * ns / n, six sigma for ns/16 independent draws + 0.2 %
+// Bracketed select (columns of >= SEL_BRACKET_MIN values with a sample buffer planned): is it?
+static bool select_is_bracketed(const SelWs& w, int64_t n, int64_t stride) {
+    return w.sample && stride == 1 && n >= SEL_BRACKET_MIN;
+}
+struct SelBracket { int64_t r_lo, r_hi; };
+static SelBracket select_bracket_ranks(const SelWs& w, int64_t n, const PctIndex& pi) {
+    // bracket from the sample: ranks around k0 * ns / n, six sigma for ns/16 independent draws + 0.2 %
     const int64_t ns = w.ns;
     const double p = (double)pi.k0 / (double)(n > 1 ? n - 1 : 1);
     const double sigma = sqrt(p * (1.0 - p) * (double)ns * 16.0);
     const int64_t margin = (int64_t)(6.0 * sigma) + ns / 500 + 16;
     const int64_t mid = (int64_t)(p * (double)(ns - 1));
-    const int64_t r_lo = mid - margin < 0 ? 0 : mid - margin;
-    const int64_t r_hi = mid + margin > ns - 1 ? ns - 1 : mid + margin;
+    SelBracket r;
+    r.r_lo = mid - margin < 0 ? 0 : mid - margin;
+    r.r_hi = mid + margin > ns - 1 ? ns - 1 : mid + margin;
+    return r;
+}
+// First half of the bracketed select: the sample and the two order statistics of it that bracket the ranks.  It
+// needs the VALUES only (src / src_stride: the column itself, or the z of the (n,3) rows it will be copied from), so the
+// fused filter runs it beside the centroid summary, before the column exists.
+static int select_sample_passes(const float* src, int64_t src_stride, int64_t n, double q_percent, SelWs& w,
+                                hipStream_t s) {
+    const PctIndex pi = pct_index(n, q_percent);
+    const SelGate always = {nullptr, nullptr, nullptr};
+    const SelBracket br = select_bracket_ranks(w, n, pi);
+    const int64_t ns = w.ns;
     PCH_LAUNCH("sel_init", selx_init_k, dim3((unsigned)ceil_div(9 * SEL_BINS, 256)), dim3(256), 0, s, w.xhist,
-               9 * SEL_BINS, w.run, 3, (unsigned long long)r_lo, (unsigned long long)r_hi, 0ull, w.br);
-    PCH_LAUNCH("sel_sample", sel_sample_k, dim3((unsigned)ceil_div(ns, 256)), dim3(256), 0, s, base, ns, w.sample);
-    {                                                      // both ends of the bracket in the same three sweeps
-        int64_t gs = ceil_div(ns, SEL_TILE);
-        if (gs > 2048) gs = 2048;
-        if (gs < 1) gs = 1;
-        const dim3 grid((unsigned)gs), blk(256);
-        PCH_LAUNCH("sel_hist0", (selx_hist_k<0, 2>), grid, blk, 0, s, (const float*)w.sample, ns, (int64_t)1, w.run, w.xhist, always);
-        PCH_LAUNCH("sel_hist1", (selx_hist_k<1, 2>), grid, blk, 0, s, (const float*)w.sample, ns, (int64_t)1, w.run, w.xhist, always);
-        PCH_LAUNCH("sel_hist2", (selx_hist_k<2, 2>), grid, blk, 0, s, (const float*)w.sample, ns, (int64_t)1, w.run, w.xhist, always);
+               9 * SEL_BINS, w.run, 3, (unsigned long long)br.r_lo, (unsigned long long)br.r_hi, 0ull, w.br);
+    PCH_LAUNCH("sel_sample", sel_sample_k, dim3((unsigned)ceil_div(ns, 1024)), dim3(256), 0, s, src, src_stride, ns,
+               w.sample);
+    int64_t gs = ceil_div(ns, SEL_TILE);                   // both ends of the bracket in the same three sweeps
+    if (gs > 2048) gs = 2048;
+    if (gs < 1) gs = 1;
+    const dim3 grid((unsigned)gs), blk(256);
+    PCH_LAUNCH("sel_hist0", (selx_hist_k<0, 2>), grid, blk, 0, s, (const float*)w.sample, ns, (int64_t)1, w.run, w.xhist, always);
+    PCH_LAUNCH("sel_hist1", (selx_hist_k<1, 2>), grid, blk, 0, s, (const float*)w.sample, ns, (int64_t)1, w.run, w.xhist, always);
+    PCH_LAUNCH("sel_hist2", (selx_hist_k<2, 2>), grid, blk, 0, s, (const float*)w.sample, ns, (int64_t)1, w.run, w.xhist, always);
+    return PCH_OK;
+}
+
+// the histogram / next passes (need only the raw values) ...
+// sample_done: select_sample_passes already ran for this column (and is ordered in front of `s`)
+static int select_passes(const float* base, int64_t n, int64_t stride, double q_percent, SelWs& w,
+                         hipStream_t s, bool sample_done = false) {
+    const PctIndex pi = pct_index(n, q_percent);
+    const SelGate always = {nullptr, nullptr, nullptr};
+    SelRun* fin = w.run + 2;
+    uint32_t* hfin = w.xhist + 6 * SEL_BINS;
+    if (!select_is_bracketed(w, n, stride)) {
+        PCH_LAUNCH("sel_init", selx_init_k, dim3((unsigned)ceil_div(9 * SEL_BINS, 256)), dim3(256), 0, s, w.xhist,
+                   9 * SEL_BINS, w.run, 3, 0ull, 0ull, (unsigned long long)pi.k0, (BrState*)nullptr);
+        return select_rounds(base, n, stride, !pi.same, fin, hfin, s, always, n);
     }
+    if (!sample_done) PCH_TRY(select_sample_passes(base, 1, n, q_percent, w, s));
+    const SelBracket br = select_bracket_ranks(w, n, pi);
+    const int64_t ns = w.ns;
     // one resident round of workgroups: 32 KB of LDS each, five per CU (a 2048-workgroup grid ran as 1280 + 768:
     // 0.191 -> 0.177 ms).  Tried and dropped (round 3): one ballot per four values and 32-bit counters (no change: the
     // sweep is not bound by its arithmetic); per-wave staging without barriers + register prefetch (0.194 ms);
@@ -590,7 +631,7 @@ static int select_passes(const float* base, int64_t n, int64_t stride, double q_
         if (gb > per_round[slot]) gb = per_round[slot];
     }
     PCH_LAUNCH("sel_bracket", sel_bracket_k, dim3((unsigned)gb), dim3(256), 0, s, base, n, (const SelRun*)w.run, w.xhist,
-               r_lo == 0 ? 1 : 0, r_hi == ns - 1 ? 1 : 0, w.br, w.cand, w.cap);
+               br.r_lo == 0 ? 1 : 0, br.r_hi == ns - 1 ? 1 : 0, w.br, w.cand, w.cap);
     PCH_LAUNCH("sel_bracket_fix", sel_bracket_fix_k, dim3(1), dim3(64), 0, s, w.br, fin, (unsigned long long)pi.k0,
                pi.same);
     // exact select: on the candidates when the bracket holds, else over the whole column - the same launches either
@@ -612,16 +653,20 @@ static int select_percentile(const float* base, int64_t n, int64_t stride, const
     return select_lerp(n, sub, q_percent, add1, add2, w, s);
 }
 
-// per-thread side stream + events: the select passes only need the raw z column, so they run
-// beside the (latency-bound, 3-wave) centroid walk
-struct SideStream { hipStream_t s; hipEvent_t ev_fork, ev_join; bool ok; };
+// per-thread side stream + events: the select passes only need the raw z values, so they run
+// beside the centroid passes (the sample half beside the summary, the sweep beside the 3-wave walk)
+struct SideStream { hipStream_t s; hipEvent_t ev_fork, ev_join, ev_start; bool ok; };
 struct SideStreams {                                    // one per device this thread has used; gone with the thread
     SideStream ss[PCH_MAX_DEVICES];
-    SideStreams() { for (auto& x : ss) x = {nullptr, nullptr, nullptr, false}; }
+    SideStreams() { for (auto& x : ss) x = {nullptr, nullptr, nullptr, nullptr, false}; }
     ~SideStreams() {
         if (!may_release_hip_objects()) return;
         for (auto& x : ss)
-            if (x.ok) { (void)hipEventDestroy(x.ev_fork); (void)hipEventDestroy(x.ev_join); (void)hipStreamDestroy(x.s); }
+            if (x.ok) {
+                (void)hipEventDestroy(x.ev_fork); (void)hipEventDestroy(x.ev_join);
+                (void)hipEventDestroy(x.ev_start);
+                (void)hipStreamDestroy(x.s);
+            }
     }
 };
 static SideStream& side_stream() {
@@ -630,7 +675,8 @@ static SideStream& side_stream() {
     if (!ss.ok) {
         if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&ss.ev_fork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.ev_join, hipEventDisableTiming) == hipSuccess)
+            hipEventCreateWithFlags(&ss.ev_join, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.ev_start, hipEventDisableTiming) == hipSuccess)
             ss.ok = true;
     }
     return ss;
@@ -1206,10 +1252,21 @@ extern "C" int pch_ground_filter_f32(const float* raw, int64_t n, double pct, fl
     bool cand_made = false;
     SideStream& ss = side_stream();
     if (ss.ok) {
+        // Two strands.  `s`: summary, level 2, walk - no cross-stream hop inside the chain.  Side stream: at once the
+        // sample half of the percentile (it reads the z of the raw rows, so it does not wait for the z column and
+        // runs beside the summary), then - behind the summary - the percentile's sweep and exact select; joined in
+        // front of the interpolation.  With the sample half out of the way both strands end within a few us of each
+        // other (measured: the other assignment, select on `s` and walk on the side stream, loses 45 us to the hops).
+        const bool early = select_is_bracketed(w.sel, n, 1);
+        if (early) {
+            PCH_HIP_TRY(hipEventRecord(ss.ev_start, s));            // everything the caller queued before this call
+            PCH_HIP_TRY(hipStreamWaitEvent(ss.s, ss.ev_start, 0));   // (the rows; the previous user of the workspace)
+            PCH_TRY(select_sample_passes(raw + 2, 3, n, pct, w.sel, ss.s));
+        }
         PCH_TRY(mean_seq_launch(raw, n, w.centroid, w.ms, w.zcol, s, ss.ev_fork, nullptr, MS_DIVIDE_BY_N, MS_PHASE_BOTH,
                                 &w.cand, &cand_made));
         PCH_HIP_TRY(hipStreamWaitEvent(ss.s, ss.ev_fork, 0));
-        PCH_TRY(select_passes(w.zcol, n, 1, pct, w.sel, ss.s));
+        PCH_TRY(select_passes(w.zcol, n, 1, pct, w.sel, ss.s, early));
         PCH_HIP_TRY(hipEventRecord(ss.ev_join, ss.s));
         PCH_HIP_TRY(hipStreamWaitEvent(s, ss.ev_join, 0));
     } else {

@@ -35,6 +35,9 @@ void ms_plan(Arena& a, int64_t n, MsWs& w);
 // centroid[3] = np.mean(xyz, axis=0) (float32).  zcol (optional, n floats) receives a copy of
 // the z column, written by the same pass that reads the tile.
 // ev_zcol (optional) is recorded on `s` right after the pass that writes zcol.
+// walk_stream (optional, needs ev_zcol): level 2 and the walk run there, behind that event, so that whatever the caller
+// enqueues on `s` next (the percentile passes over zcol) starts without a cross-stream hop; the caller joins
+// walk_stream before it reads `out`.
 // sum_in (optional, device float[3]): running sum to continue instead of +0.0; divide_n: MS_DIVIDE_BY_N (the
 // mean of these n rows), MS_NO_DIVIDE (out = the running sum after the rows) or the row count to divide by.
 // phase: both kernels groups (default), only the tables (summary + level 2: they do not depend on sum_in), or only
@@ -45,7 +48,8 @@ constexpr int MS_PHASE_BOTH = 0, MS_PHASE_TABLES = 1, MS_PHASE_WALK = 2;
 // estimate, i.e. an array of at least two 65 536-row groups and prediction enabled)
 int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zcol, hipStream_t s,
                     hipEvent_t ev_zcol = nullptr, const float* sum_in = nullptr, int64_t divide_n = MS_DIVIDE_BY_N,
-                    int phase = MS_PHASE_BOTH, const MsCand* cand = nullptr, bool* cand_made = nullptr);
+                    int phase = MS_PHASE_BOTH, const MsCand* cand = nullptr, bool* cand_made = nullptr,
+                    hipStream_t walk_stream = nullptr);
 int mean_seq_serial_launch(const float* xyz, int64_t n, float* out, hipStream_t s);
 
 }  // namespace pch

@@ -971,8 +971,9 @@ void ms_plan(Arena& a, int64_t n, MsWs& w) {
 
 int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zcol, hipStream_t s,
                     hipEvent_t ev_zcol, const float* sum_in, int64_t divide_n, int phase, const MsCand* cand,
-                    bool* cand_made) {
+                    bool* cand_made, hipStream_t walk_stream) {
     if (cand_made) *cand_made = false;
+    hipStream_t ws = s;                                  // stream of level 2 and the walk
     const int64_t nb = n > 0 ? ceil_div(n, MSB) : 0;
     const int64_t nb2 = ceil_div(nb, 64);
     if (n > 0 && phase != MS_PHASE_WALK) {
@@ -996,7 +997,11 @@ int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zco
                    0, s, xyz, n, nb, w.rec, zcol, pred, nb2, emit ? cand->slots : (float4*)nullptr,
                    emit ? cand->counts : (uint32_t*)nullptr, emit ? (const float*)cand->tcand : (const float*)nullptr);
         if (ev_zcol) PCH_HIP_TRY(hipEventRecord(ev_zcol, s));
-        PCH_LAUNCH("mean_level2", ms_level2_k, dim3((unsigned)(3 * nb2)), dim3(256), 0, s,
+        if (walk_stream && ev_zcol) {
+            PCH_HIP_TRY(hipStreamWaitEvent(walk_stream, ev_zcol, 0));
+            ws = walk_stream;
+        }
+        PCH_LAUNCH("mean_level2", ms_level2_k, dim3((unsigned)(3 * nb2)), dim3(256), 0, ws,
                    (const MsRec*)w.rec, nb, nb2, w.hdr2, w.rows2);
     }
     if (phase == MS_PHASE_TABLES) return PCH_OK;
@@ -1004,7 +1009,7 @@ int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zco
     T.rec = w.rec; T.nb = nb;
     T.hdr2 = w.hdr2; T.rows2 = w.rows2; T.nb2 = nb2;
     const int divide = divide_n != MS_NO_DIVIDE;
-    PCH_LAUNCH("mean_walk", ms_walk_k, dim3(3), dim3(64), 0, s, xyz, n, T, sum_in,
+    PCH_LAUNCH("mean_walk", ms_walk_k, dim3(3), dim3(64), 0, ws, xyz, n, T, sum_in,
                divide_n == MS_DIVIDE_BY_N ? n : divide_n, divide, out, w.stats);
     return PCH_OK;
 }
