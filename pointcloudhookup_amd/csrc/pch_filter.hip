@@ -858,60 +858,71 @@ constexpr int GF_CW_BLKS = GF_CT_BLKS / (GF_THREADS / 64);     // 16 slots per w
 
 template <int WHICH>
 __global__ __launch_bounds__(GF_THREADS) void gf_cand_k(
-    const float4* __restrict__ slots, const uint32_t* __restrict__ counts, const float* __restrict__ tcand,
+    const float* __restrict__ slots, const uint32_t* __restrict__ counts, const float* __restrict__ tcand,
     int64_t nblk, const float* __restrict__ centroid, const float* __restrict__ scal, GfState* __restrict__ st,
     uint64_t* __restrict__ status, long long min_keep, float* __restrict__ out_points,
     int32_t* __restrict__ out_index) {
+    constexpr int NR = GF_CSLOT / 64;                      // rounds of 64 rows in a slot
+    constexpr int64_t SLOT_WORDS = 4 * GF_CSLOT;           // planes x | y | z | row-in-block (MsCand, pch_mean.h)
+    constexpr int NE = GF_CW_BLKS * NR;                    // (slot, round) pairs of a wave
     __shared__ uint32_t wtot[GF_THREADS / 64];
     __shared__ uint32_t excl_sh;
     __shared__ uint32_t box[GF_THREADS / 64][6];
-    __shared__ unsigned long long masks[GF_THREADS / 64][GF_CW_BLKS][GF_CSLOT / 64];     // 4 KB
+    __shared__ unsigned long long masks[GF_THREADS / 64][NE];        // survivors of every (slot, round): 4 KB
+    __shared__ uint32_t cum[GF_THREADS / 64][NE];                     // survivors of the wave in front of that pair
     __shared__ uint32_t tile_sh;
+    static_assert(NE == 128, "two (slot, round) pairs per lane in the prefix below");
     if (!gf_cand_ok(tcand, centroid, scal)) return;        // gf_compact_k runs instead
     if (WHICH == 1 && st->use_b == 0) return;
+#ifdef PCH_GF_STAMPS
+    const unsigned long long ts0 = wall_clock64();
+    unsigned long long ts1 = 0, ts2 = 0, ts3 = 0;
+#endif
     if (threadIdx.x == 0) tile_sh = atomicAdd(&st->ticket[WHICH], 1u);     // tile order = order of arrival (look-back)
+    const int w = wave_id(), l = lane_id();
+    masks[w][2 * l] = 0ull;
+    masks[w][2 * l + 1] = 0ull;
     __syncthreads();
     const int64_t tile = tile_sh;
     const float cx = centroid[0], cy = centroid[1], cz = centroid[2];
     const float thr = scal[1 + WHICH];
-    const int w = wave_id(), l = lane_id();
     const int64_t b0 = tile * GF_CT_BLKS + (int64_t)w * GF_CW_BLKS;
-    // Candidates come in runs: blocks next to a tower hold hundreds, most blocks few or none.  A wave therefore takes
-    // its slots one at a time with ALL rounds of the slot in flight at once (up to eight 16-byte loads per lane).
-    constexpr int NR = GF_CSLOT / 64;
-    auto load_slot = [&](int64_t b, uint32_t nc, float4 (&q)[NR]) {
-        const float4* __restrict__ slot = slots + b * GF_CSLOT;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            q[r].x = q[r].y = q[r].z = q[r].w = 0.0f;
-            if ((uint32_t)(r * 64) < nc) {                 // wave-uniform: rounds beyond the slot's count cost nothing
-                const uint32_t i = r * 64 + l;
-                if (i < nc) q[r] = slot[i];
-            }
-        }
-    };
+    // Candidates come in runs: blocks next to a tower hold hundreds, most blocks fewer than 64 or none.  A slot after
+    // the other is a chain of dependent memory round trips (the kernel waited 86 % of its wave cycles that way), so
+    // the wave goes ROUND-major: round r of all its 16 slots at once - 16 independent loads in flight, of the z PLANE
+    // alone in the counting phase (a quarter of the slot's bytes) - and usually one or two rounds are all there is.
     uint32_t ncs[GF_CW_BLKS];
+    uint32_t maxnc = 0;
 #pragma unroll
-    for (int kb = 0; kb < GF_CW_BLKS; ++kb) ncs[kb] = (b0 + kb) < nblk ? counts[b0 + kb] : 0u;
+    for (int kb = 0; kb < GF_CW_BLKS; ++kb) {
+        ncs[kb] = (b0 + kb) < nblk ? counts[b0 + kb] : 0u;
+        maxnc = ncs[kb] > maxnc ? ncs[kb] : maxnc;
+    }
+    maxnc = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxnc);      // (every lane read the same words)
     uint32_t run = 0;
 #pragma unroll 1
-    for (int kb = 0; kb < GF_CW_BLKS; ++kb) {
-        const uint32_t nc = ncs[kb];
-        if (nc == 0) continue;                             // wave-uniform
-        float4 q[NR];
-        load_slot(b0 + kb, nc, q);
+    for (int r = 0; r < NR; ++r) {
+        if ((uint32_t)(r * 64) >= maxnc) break;            // wave-uniform
+        const uint32_t i = r * 64 + l;
+        float z[GF_CW_BLKS];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            if ((uint32_t)(r * 64) >= nc) break;
-            const uint32_t i = r * 64 + l;
-            const bool keep = i < nc && (q[r].z - cz) > thr;            // points = raw_points - centroid (float32)
+        for (int kb = 0; kb < GF_CW_BLKS; ++kb) {
+            z[kb] = 0.0f;
+            if (i < ncs[kb]) z[kb] = slots[(b0 + kb) * SLOT_WORDS + 2 * GF_CSLOT + i];
+        }
+#pragma unroll
+        for (int kb = 0; kb < GF_CW_BLKS; ++kb) {
+            const bool keep = i < ncs[kb] && (z[kb] - cz) > thr;        // points = raw_points - centroid (float32)
             const unsigned long long m = __ballot(keep);
-            if (l == 0) masks[w][kb][r] = m;
+            if (l == 0 && m) masks[w][kb * NR + r] = m;
             run += (uint32_t)__popcll(m);
         }
     }
     if (l == 0) wtot[w] = run;
     __syncthreads();
+#ifdef PCH_GF_STAMPS
+    ts1 = wall_clock64();
+#endif
     const uint32_t T = wtot[0] + wtot[1] + wtot[2] + wtot[3];
     if (w == 0) {
         const uint32_t e0 = gf_lookback(status, tile, T);
@@ -926,6 +937,15 @@ __global__ __launch_bounds__(GF_THREADS) void gf_cand_k(
                 if (WHICH == 0) st->use_b = ((long long)(e + T) < min_keep) ? 1u : 0u;
             }
         }
+#ifdef PCH_GF_STAMPS
+        ts2 = wall_clock64();
+#endif
+    }
+    {   // survivors of the wave in front of every (slot, round) pair, in file order = slot-major
+        const uint32_t c0 = (uint32_t)__popcll(masks[w][2 * l]), c1 = (uint32_t)__popcll(masks[w][2 * l + 1]);
+        const uint32_t incl = wave_scan_incl(c0 + c1);
+        cum[w][2 * l] = incl - c0 - c1;
+        cum[w][2 * l + 1] = incl - c1;
     }
     __syncthreads();
     if (T == 0) return;                                    // workgroup-uniform
@@ -934,35 +954,48 @@ __global__ __launch_bounds__(GF_THREADS) void gf_cand_k(
     uint32_t lo[3] = {0u, 0u, 0u}, hi[3] = {0u, 0u, 0u};  // lo holds ~ordered(min)
     const uint64_t lt = lanemask_lt();
 #pragma unroll 1
-    for (int kb = 0; kb < GF_CW_BLKS; ++kb) {
-        const uint32_t nc = ncs[kb];
-        if (nc == 0) continue;
-        const int64_t b = b0 + kb;
-        float4 q[NR];
-        load_slot(b, nc, q);                               // the same lines again: they are in L2 now
+    for (int r = 0; r < NR; ++r) {
+        if ((uint32_t)(r * 64) >= maxnc) break;
+        const uint32_t i = r * 64 + l;
+        // eight slots at a time: with all sixteen rows in registers the kernel needs 130 VGPRs, and at three waves
+        // per SIMD only half of the tiles are resident - two rounds of workgroups that each wait on the look-back
+        constexpr int HB = GF_CW_BLKS / 2;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            if ((uint32_t)(r * 64) >= nc) break;
-            const unsigned long long m = masks[w][kb][r];
-            if (m == 0) continue;
-            if ((m >> l) & 1ull) {
-                const float4 c4 = q[r];
-                const float v[3] = {c4.x - cx, c4.y - cy, c4.z - cz};
-                const int64_t o = (int64_t)woff + (uint32_t)__popcll(m & lt);
-                out_points[3 * o + 0] = v[0];
-                out_points[3 * o + 1] = v[1];
-                out_points[3 * o + 2] = v[2];
-                if (out_index) out_index[o] = (int32_t)(b * GF_CBLK + (int64_t)__float_as_uint(c4.w));
-                if (fabsf(v[0]) < INFINITY && fabsf(v[1]) < INFINITY && fabsf(v[2]) < INFINITY) {   // NaN/inf rows
+        for (int half = 0; half < 2; ++half) {
+            float4 q[HB];
+            unsigned long long ms[HB];
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        const uint32_t kk = f32_ordered(v[a]);
-                        lo[a] = ~kk > lo[a] ? ~kk : lo[a];
-                        hi[a] = kk > hi[a] ? kk : hi[a];
+            for (int k = 0; k < HB; ++k) {                 // the four planes, survivors only
+                const int kb = half * HB + k;
+                ms[k] = masks[w][kb * NR + r];
+                q[k].x = q[k].y = q[k].z = q[k].w = 0.0f;
+                if ((ms[k] >> l) & 1ull) {
+                    const float* __restrict__ sp = slots + (b0 + kb) * SLOT_WORDS + i;
+                    q[k].x = sp[0]; q[k].y = sp[GF_CSLOT]; q[k].z = sp[2 * GF_CSLOT]; q[k].w = sp[3 * GF_CSLOT];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const int kb = half * HB + k;
+                const unsigned long long m = ms[k];
+                if ((m >> l) & 1ull) {
+                    const float4 c4 = q[k];
+                    const float v[3] = {c4.x - cx, c4.y - cy, c4.z - cz};
+                    const int64_t o = (int64_t)woff + cum[w][kb * NR + r] + (uint32_t)__popcll(m & lt);
+                    out_points[3 * o + 0] = v[0];
+                    out_points[3 * o + 1] = v[1];
+                    out_points[3 * o + 2] = v[2];
+                    if (out_index) out_index[o] = (int32_t)((b0 + kb) * GF_CBLK + (int64_t)__float_as_uint(c4.w));
+                    if (fabsf(v[0]) < INFINITY && fabsf(v[1]) < INFINITY && fabsf(v[2]) < INFINITY) {   // NaN/inf rows
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            const uint32_t kk = f32_ordered(v[a]);
+                            lo[a] = ~kk > lo[a] ? ~kk : lo[a];
+                            hi[a] = kk > hi[a] ? kk : hi[a];
+                        }
                     }
                 }
             }
-            woff += (uint32_t)__popcll(m);
         }
     }
 #pragma unroll
@@ -978,6 +1011,13 @@ __global__ __launch_bounds__(GF_THREADS) void gf_cand_k(
         for (int w2 = 1; w2 < GF_THREADS / 64; ++w2) v = box[w2][a] > v ? box[w2][a] : v;
         if (v) atomicMax(&st->slots[WHICH][tile % GF_SLOTS][a], v);
     }
+#ifdef PCH_GF_STAMPS
+    ts3 = wall_clock64();
+    if (WHICH == 0 && threadIdx.x == 0 && (tile % 190 == 0 || tile == gridDim.x - 1))
+        printf("gf_cand tile %4lld (block %4u): start %8.2f us, count %6.2f, look-back %6.2f, rows %6.2f, end %8.2f us\n",
+               (long long)tile, blockIdx.x, (double)(ts0 % 100000000ull) / 100.0, (double)(ts1 - ts0) / 100.0,
+               (double)(ts2 - ts1) / 100.0, (double)(ts3 - ts2) / 100.0, (double)(ts3 % 100000000ull) / 100.0);
+#endif
 }
 
 // publishes the scalars, the count and the bounding box of the sweep that counts
@@ -1029,7 +1069,7 @@ static void gf_plan(Arena& a, int64_t n, GfWs& w) {
     w.cand.tcand = a.take<float>(4);
     w.cand.counts = a.take<uint32_t>(nblk);
     w.cand.zsample = a.take<float>(nblk);
-    w.cand.slots = a.take<float4>(nblk * MS_CAND_SLOT);    // 8 KB per 1024-row block
+    w.cand.slots = a.take<float>(nblk * 4 * MS_CAND_SLOT); // 8 KB per 1024-row block: four planes (MsCand)
     w.cand.pct = 0.0;
     w.cand.add = 0.0f;
 }
@@ -1283,10 +1323,10 @@ extern "C" int pch_ground_filter_f32(const float* raw, int64_t n, double pct, fl
         // then return at once - and the other way round.  Same tiles, same tickets, same look-back words.
         const int64_t nblk = ceil_div(n, GF_CBLK);
         const dim3 cgrid((unsigned)ceil_div(nblk, GF_CT_BLKS));
-        PCH_LAUNCH("gf_cand", gf_cand_k<0>, cgrid, blk, 0, s, (const float4*)w.cand.slots, (const uint32_t*)w.cand.counts,
+        PCH_LAUNCH("gf_cand", gf_cand_k<0>, cgrid, blk, 0, s, (const float*)w.cand.slots, (const uint32_t*)w.cand.counts,
                    tcand, nblk, (const float*)w.centroid, (const float*)w.sel.scal, w.st, w.status, (long long)min_keep,
                    out_points, out_index);
-        PCH_LAUNCH("gf_cand_fb", gf_cand_k<1>, cgrid, blk, 0, s, (const float4*)w.cand.slots,
+        PCH_LAUNCH("gf_cand_fb", gf_cand_k<1>, cgrid, blk, 0, s, (const float*)w.cand.slots,
                    (const uint32_t*)w.cand.counts, tcand, nblk, (const float*)w.centroid, (const float*)w.sel.scal, w.st,
                    w.status + nb, (long long)min_keep, out_points, out_index);
     }

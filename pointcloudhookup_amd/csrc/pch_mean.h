@@ -9,15 +9,17 @@ struct MsRec;
 struct MsPred;
 // Candidate rows for the height filter, emitted by the summary pass while it has the rows in LDS anyway (pch_filter.hip,
 // gf_cand_k): rows whose RAW z exceeds `tcand`, a deliberately low estimate of the filter's threshold.
-//   slots  [nb][MS_CAND_SLOT] float4 (x, y, z, bits of the row's index inside its 1024-row block), file order inside
-//          a block.  A slot holds half of its block: typical data keeps ~10 % of the rows (a block next to a tower in
+//   slots  [nb][4][MS_CAND_SLOT] words: four PLANES per block - x, y, z and the bits of the row's index inside its
+//          1024-row block - file order inside a block.  Planes, not float4 rows: the sweep first counts survivors
+//          from the z plane alone (a quarter of the bytes) and then reads the rows once; as rows it pulled every line
+//          twice (0.55 GB for 0.35 GB of necessary traffic).  A slot holds half of its block: typical data keeps ~10 % of the rows (a block next to a tower in
 //          flight-line order more), and slots that are 8 KB apart instead of 16 KB are what makes their reads and writes stream; a block with more candidates
 //          raises the overflow word and the sweep then reads the tile as before
 //   counts [nb]       rows used in every slot
 //   tcand  [2]        [0] the threshold that was used (device; written before the summary runs), [1] overflow word
 constexpr int MS_CAND_SLOT = 512;
 struct MsCand {
-    float4*   slots;
+    float*    slots;
     uint32_t* counts;
     float*    tcand;
     float*    zsample;           // [nb] one sampled z per block (scratch of the estimate)

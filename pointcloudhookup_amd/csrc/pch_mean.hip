@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
                                                              int64_t nb, MsRec* __restrict__ recs,
                                                              float* __restrict__ zcol,
                                                              const MsPred* __restrict__ pred, int64_t nb2,
-                                                             float4* __restrict__ cslots, uint32_t* __restrict__ ccounts,
+                                                             float* __restrict__ cslots, uint32_t* __restrict__ ccounts,
                                                              const float* __restrict__ tcand) {
     __shared__ __attribute__((aligned(16))) float lds[MS_WAVES][MSB * 3];
     __shared__ MsRec stage[MS_WAVES];                    // a record is assembled here, stored as whole lines
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
     if (cslots) {
         // candidate rows of the height filter (MsCand): raw z above the low threshold estimate, kept in file order
         const float tc = *tcand;
-        float4* slot = cslots + blk * MS_CAND_SLOT;
+        float* slot = cslots + blk * (4 * MS_CAND_SLOT);        // planes x | y | z | row (MsCand)
         uint32_t at = 0;
 #pragma unroll
         for (int i = 0; i < MS_PER; ++i) {
@@ -314,9 +314,10 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
             const unsigned long long m = __ballot(take);
             const uint32_t pos = at + (uint32_t)__popcll(m & lanemask_lt());
             if (take && pos < (uint32_t)MS_CAND_SLOT) {
-                float4 q;
-                q.x = tile[3 * p]; q.y = tile[3 * p + 1]; q.z = z; q.w = __uint_as_float((uint32_t)p);
-                slot[pos] = q;
+                slot[pos] = tile[3 * p];
+                slot[MS_CAND_SLOT + pos] = tile[3 * p + 1];
+                slot[2 * MS_CAND_SLOT + pos] = z;
+                slot[3 * MS_CAND_SLOT + pos] = __uint_as_float((uint32_t)p);
             }
             at += (uint32_t)__popcll(m);
         }
@@ -994,7 +995,7 @@ int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zco
         }
         const bool emit = cand && cand_made && *cand_made;
         PCH_LAUNCH("mean_summary", ms_summary_k, dim3((unsigned)ceil_div(nb, MS_WAVES)), dim3(64 * MS_WAVES),
-                   0, s, xyz, n, nb, w.rec, zcol, pred, nb2, emit ? cand->slots : (float4*)nullptr,
+                   0, s, xyz, n, nb, w.rec, zcol, pred, nb2, emit ? cand->slots : (float*)nullptr,
                    emit ? cand->counts : (uint32_t*)nullptr, emit ? (const float*)cand->tcand : (const float*)nullptr);
         if (ev_zcol) PCH_HIP_TRY(hipEventRecord(ev_zcol, s));
         if (walk_stream && ev_zcol) {
