@@ -857,7 +857,7 @@ constexpr int GF_CT_BLKS = 64;                         // slots per workgroup: 6
 constexpr int GF_CW_BLKS = GF_CT_BLKS / (GF_THREADS / 64);     // 16 slots per wave, taken in groups of four
 
 template <int WHICH>
-__global__ __launch_bounds__(GF_THREADS) void gf_cand_k(
+__global__ __launch_bounds__(GF_THREADS, 6) void gf_cand_k(     // six waves per SIMD: every tile of a 100 M-point call resident
     const float* __restrict__ slots, const uint32_t* __restrict__ counts, const float* __restrict__ tcand,
     int64_t nblk, const float* __restrict__ centroid, const float* __restrict__ scal, GfState* __restrict__ st,
     uint64_t* __restrict__ status, long long min_keep, float* __restrict__ out_points,
@@ -924,6 +924,53 @@ __global__ __launch_bounds__(GF_THREADS) void gf_cand_k(
     ts1 = wall_clock64();
 #endif
     const uint32_t T = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    // eight slots at a time: with all sixteen rows in registers the kernel needs 130 VGPRs, and at three waves per
+    // SIMD only half of the tiles are resident - two rounds of workgroups that each wait on the look-back
+    constexpr int HB = GF_CW_BLKS / 2;
+    const uint64_t lt = lanemask_lt();
+    uint32_t lo[3] = {0u, 0u, 0u}, hi[3] = {0u, 0u, 0u};  // lo holds ~ordered(min)
+    auto load_half = [&](int r, int half, float4 (&q)[HB], unsigned long long (&ms)[HB]) {
+        const uint32_t i = r * 64 + l;
+#pragma unroll
+        for (int k = 0; k < HB; ++k) {                     // the four planes, survivors only
+            const int kb = half * HB + k;
+            ms[k] = masks[w][kb * NR + r];
+            q[k].x = q[k].y = q[k].z = q[k].w = 0.0f;
+            if ((ms[k] >> l) & 1ull) {
+                const float* __restrict__ sp = slots + (b0 + kb) * SLOT_WORDS + i;
+                q[k].x = sp[0]; q[k].y = sp[GF_CSLOT]; q[k].z = sp[2 * GF_CSLOT]; q[k].w = sp[3 * GF_CSLOT];
+            }
+        }
+    };
+    auto emit_half = [&](int r, int half, const float4 (&q)[HB], const unsigned long long (&ms)[HB], uint32_t woff) {
+#pragma unroll
+        for (int k = 0; k < HB; ++k) {
+            const int kb = half * HB + k;
+            const unsigned long long m = ms[k];
+            if ((m >> l) & 1ull) {
+                const float4 c4 = q[k];
+                const float v[3] = {c4.x - cx, c4.y - cy, c4.z - cz};
+                const int64_t o = (int64_t)woff + cum[w][kb * NR + r] + (uint32_t)__popcll(m & lt);
+                out_points[3 * o + 0] = v[0];
+                out_points[3 * o + 1] = v[1];
+                out_points[3 * o + 2] = v[2];
+                if (out_index) out_index[o] = (int32_t)((b0 + kb) * GF_CBLK + (int64_t)__float_as_uint(c4.w));
+                if (fabsf(v[0]) < INFINITY && fabsf(v[1]) < INFINITY && fabsf(v[2]) < INFINITY) {   // NaN/inf rows
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const uint32_t kk = f32_ordered(v[a]);
+                        lo[a] = ~kk > lo[a] ? ~kk : lo[a];
+                        hi[a] = kk > hi[a] ? kk : hi[a];
+                    }
+                }
+            }
+        }
+    };
+    // the rows of the first half-batch are requested BEFORE the look-back: the loads need no output offset (only the
+    // stores do), and a tile waits ~30 us for the tiles in front of it with nothing of its own in flight otherwise
+    float4 q0[HB];
+    unsigned long long ms0[HB];
+    if (T != 0 && maxnc != 0) load_half(0, 0, q0, ms0);
     if (w == 0) {
         const uint32_t e0 = gf_lookback(status, tile, T);
         const bool lb_failed = e0 == GF_LB_FAILED;
@@ -951,50 +998,23 @@ __global__ __launch_bounds__(GF_THREADS) void gf_cand_k(
     if (T == 0) return;                                    // workgroup-uniform
     uint32_t woff = excl_sh;
     for (int w2 = 0; w2 < w; ++w2) woff += wtot[w2];
-    uint32_t lo[3] = {0u, 0u, 0u}, hi[3] = {0u, 0u, 0u};  // lo holds ~ordered(min)
-    const uint64_t lt = lanemask_lt();
-#pragma unroll 1
-    for (int r = 0; r < NR; ++r) {
-        if ((uint32_t)(r * 64) >= maxnc) break;
-        const uint32_t i = r * 64 + l;
-        // eight slots at a time: with all sixteen rows in registers the kernel needs 130 VGPRs, and at three waves
-        // per SIMD only half of the tiles are resident - two rounds of workgroups that each wait on the look-back
-        constexpr int HB = GF_CW_BLKS / 2;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
+    if (maxnc != 0) {
+        emit_half(0, 0, q0, ms0, woff);
+        {
             float4 q[HB];
             unsigned long long ms[HB];
+            load_half(0, 1, q, ms);
+            emit_half(0, 1, q, ms, woff);
+        }
+#pragma unroll 1
+        for (int r = 1; r < NR; ++r) {
+            if ((uint32_t)(r * 64) >= maxnc) break;
 #pragma unroll
-            for (int k = 0; k < HB; ++k) {                 // the four planes, survivors only
-                const int kb = half * HB + k;
-                ms[k] = masks[w][kb * NR + r];
-                q[k].x = q[k].y = q[k].z = q[k].w = 0.0f;
-                if ((ms[k] >> l) & 1ull) {
-                    const float* __restrict__ sp = slots + (b0 + kb) * SLOT_WORDS + i;
-                    q[k].x = sp[0]; q[k].y = sp[GF_CSLOT]; q[k].z = sp[2 * GF_CSLOT]; q[k].w = sp[3 * GF_CSLOT];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < HB; ++k) {
-                const int kb = half * HB + k;
-                const unsigned long long m = ms[k];
-                if ((m >> l) & 1ull) {
-                    const float4 c4 = q[k];
-                    const float v[3] = {c4.x - cx, c4.y - cy, c4.z - cz};
-                    const int64_t o = (int64_t)woff + cum[w][kb * NR + r] + (uint32_t)__popcll(m & lt);
-                    out_points[3 * o + 0] = v[0];
-                    out_points[3 * o + 1] = v[1];
-                    out_points[3 * o + 2] = v[2];
-                    if (out_index) out_index[o] = (int32_t)((b0 + kb) * GF_CBLK + (int64_t)__float_as_uint(c4.w));
-                    if (fabsf(v[0]) < INFINITY && fabsf(v[1]) < INFINITY && fabsf(v[2]) < INFINITY) {   // NaN/inf rows
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) {
-                            const uint32_t kk = f32_ordered(v[a]);
-                            lo[a] = ~kk > lo[a] ? ~kk : lo[a];
-                            hi[a] = kk > hi[a] ? kk : hi[a];
-                        }
-                    }
-                }
+            for (int half = 0; half < 2; ++half) {
+                float4 q[HB];
+                unsigned long long ms[HB];
+                load_half(r, half, q, ms);
+                emit_half(r, half, q, ms, woff);
             }
         }
     }
