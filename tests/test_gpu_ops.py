@@ -168,6 +168,34 @@ def test_mean_seq_distributions(cuda, name):
         np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+def test_mean_seq_hard_stretches_and_ragged_end(cuda):
+    """The exact path of the centroid walk is the sequential chain itself (ms_blocks_exact: 64 broadcast rounds of 16
+    register-held elements), and behind a failing block that left its binade the walk adds a doubling run of blocks
+    without consulting the tables.  Columns built for that: a zero-mean stretch of 1.5 M rows that turns into a
+    growing sum (the blind runs reach their cap of 32 and must be dropped again), a column that is hard, easy, hard
+    again, and one that is hard up to its ragged last block (rows beyond the end count as -0.0, and the running sum
+    IS -0.0 for the first rows of that column)."""
+    rng = np.random.default_rng(77)
+    n = 3_000_017                                              # 2929 full blocks + 721 rows
+    a = rng.normal(0, 0.05, n)
+    a[1_500_000:] = np.abs(rng.normal(20, 5, n - 1_500_000))
+    b = rng.normal(0, 3.0, n)
+    b[700_000:1_900_000] = rng.uniform(400, 500, 1_200_000)
+    b[1_900_000:] = rng.normal(-450 * 1.2e6 / (n - 1_900_000), 3.0, n - 1_900_000)   # walks the sum back through zero
+    c = rng.normal(0, 1e-3, n)
+    c[:5000] = -0.0
+    raw = np.column_stack([a, b, c]).astype(np.float32)
+    got = ops.mean_seq_f32(_dev(raw, cuda)).cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.uint32), np.mean(raw, axis=0).view(np.uint32))
+    # the same rows as a filter input: the percentile's sample half now reads the raw rows beside the summary
+    ref = ogf.ground_filter(raw)
+    flt = ops.ground_filter(_dev(raw, cuda))
+    np.testing.assert_array_equal(flt["centroid"].view(np.uint32), ref["centroid"].view(np.uint32))
+    assert np.float32(flt["threshold"]).view(np.uint32) == ref["threshold"].view(np.uint32)
+    assert flt["count"] == len(ref["filtered"])
+    np.testing.assert_array_equal(flt["index"].cpu().numpy(), np.flatnonzero(ref["keep"]))
+
+
 def _chained(raw, cuts, cuda):
     """np.mean over shards chained in file order: running sums handed from shard to shard, the last one divides"""
     run = None
@@ -460,17 +488,22 @@ def test_dbscan_chunk_local_sort_equals_global_sort(cuda):
     X = X[rng.permutation(n)]
     X[60001, 2] = np.nan
     dev = _dev(X, cuda)
-    for chunk in (50000, 7777, 1000, 0):
+    # chunk sizes around the sort kernel's 4096-row tile (its full and ragged tiles are separate code: exact
+    # multiples, one row more, less than a tile, the largest chunk it takes) and cell sizes that make the chunk's
+    # relative key need one, two and three passes (first / last pass are separate instantiations too)
+    cases = [(8.0, 80, c) for c in (50000, 7777, 1000, 0, 4096, 8192, 4097, 100, 131072)]
+    cases += [(60.0, 80, 50000), (60.0, 80, 4096), (0.7, 5, 50000), (0.7, 5, 8192), (0.2, 3, 20000)]
+    for eps, ms, chunk in cases:
         try:
             ops.set_dbscan_sort_mode("chunk")
-            la, ca, ka = ops.dbscan(dev, 8.0, 80, chunk, want_core=True)
+            la, ca, ka = ops.dbscan(dev, eps, ms, chunk, want_core=True)
             ops.set_dbscan_sort_mode("global")
-            lb, cb, kb = ops.dbscan(dev, 8.0, 80, chunk, want_core=True)
+            lb, cb, kb = ops.dbscan(dev, eps, ms, chunk, want_core=True)
         finally:
             ops.set_dbscan_sort_mode("auto")                       # the library's own choice (by chunk count)
-        lc, cc, kc = ops.dbscan(dev, 8.0, 80, chunk, want_core=True)
-        assert ka == kb == kc
-        assert torch.equal(la, lb) and torch.equal(ca, cb) and torch.equal(la, lc) and torch.equal(ca, cc)
+        lc, cc, kc = ops.dbscan(dev, eps, ms, chunk, want_core=True)
+        assert ka == kb == kc, (eps, ms, chunk)
+        assert torch.equal(la, lb) and torch.equal(ca, cb) and torch.equal(la, lc) and torch.equal(ca, cc), (eps, ms, chunk)
 
 
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1023, 1024, 1025, 16383, 16384, 16385, 32769, 70001])
