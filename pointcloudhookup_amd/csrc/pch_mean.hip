@@ -302,24 +302,39 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         }
     }
     if (cslots) {
-        // candidate rows of the height filter (MsCand): raw z above the low threshold estimate, kept in file order
+        // candidate rows of the height filter (MsCand): raw z above the low threshold estimate, kept in file order.
+        // Candidates come in runs (rows next to a tower); most blocks hold none, and a block whose largest z does not
+        // exceed the estimate skips the sixteen rounds of ballots, ranks and plane stores (a quarter of this kernel's
+        // vector instructions) for one wave maximum.
         const float tc = *tcand;
-        float* slot = cslots + blk * (4 * MS_CAND_SLOT);        // planes x | y | z | row (MsCand)
-        uint32_t at = 0;
+        float zr[MS_PER];
+        float zmax = -INFINITY;
 #pragma unroll
         for (int i = 0; i < MS_PER; ++i) {
             const int p = i * 64 + l;
-            const float z = tile[3 * p + 2];
-            const bool take = p < cnt && z > tc;
-            const unsigned long long m = __ballot(take);
-            const uint32_t pos = at + (uint32_t)__popcll(m & lanemask_lt());
-            if (take && pos < (uint32_t)MS_CAND_SLOT) {
-                slot[pos] = tile[3 * p];
-                slot[MS_CAND_SLOT + pos] = tile[3 * p + 1];
-                slot[2 * MS_CAND_SLOT + pos] = z;
-                slot[3 * MS_CAND_SLOT + pos] = __uint_as_float((uint32_t)p);
+            zr[i] = tile[3 * p + 2];
+            if (p < cnt) zmax = fmaxf(zmax, zr[i]);            // (NaN never exceeds anything: not a candidate either)
+        }
+        const bool some = __ballot(zmax > tc) != 0;
+        uint32_t at = 0;
+        if (some) {
+            float* slot = cslots + blk * (4 * MS_CAND_SLOT);    // planes x | y | z | row (MsCand)
+#pragma unroll
+            for (int i = 0; i < MS_PER; ++i) {
+                const int p = i * 64 + l;
+                const float z = zr[i];
+                const bool take = p < cnt && z > tc;
+                const unsigned long long m = __ballot(take);
+                if (m == 0) continue;                           // wave-uniform
+                const uint32_t pos = at + (uint32_t)__popcll(m & lanemask_lt());
+                if (take && pos < (uint32_t)MS_CAND_SLOT) {
+                    slot[pos] = tile[3 * p];
+                    slot[MS_CAND_SLOT + pos] = tile[3 * p + 1];
+                    slot[2 * MS_CAND_SLOT + pos] = z;
+                    slot[3 * MS_CAND_SLOT + pos] = __uint_as_float((uint32_t)p);
+                }
+                at += (uint32_t)__popcll(m);
             }
-            at += (uint32_t)__popcll(m);
         }
         if (l == 0) {
             ccounts[blk] = at < (uint32_t)MS_CAND_SLOT ? at : (uint32_t)MS_CAND_SLOT;
@@ -499,16 +514,25 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         }
         MsRec* rec = &stage[wave_id()];
         if (live && cmask != MS_ALLCAND) {
-            // four sums only: each is split into a low 16-bit and a high part per lane (|sum| <= 2^27), so that both
-            // wave totals fit 32 bits, and put together again in 64 bits
+            // four sums only, reduced together: two lane-swap steps (see ms_wave_all) fold the halves and the row
+            // pairs and leave candidate j0 + c in row c of the wave (16 lanes, |partial| <= 2^29), one 32-bit and
+            // three 64-bit rotations inside the row finish it - ~20 instructions where one butterfly per sum and
+            // 16-bit half took ~80
+            static_assert(MS_WIN == 4, "one window candidate per row of 16 lanes");
             if (l < MS_CAND) rec->S[l] = 0;
             __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < MS_WIN; ++k) {
-                const uint32_t lo = ms_wave_all((uint32_t)W[k] & 0xFFFFu, [](uint32_t a, uint32_t b) { return a + b; });
-                const uint32_t hi = ms_wave_all((uint32_t)(W[k] >> 16), [](uint32_t a, uint32_t b) { return a + b; });
-                if (l == 0) rec->S[j0 + k] = ((long long)(int)hi << 16) + (long long)lo;
-            }
+            const auto r02 = __builtin_amdgcn_permlane32_swap((uint32_t)W[0], (uint32_t)W[2], false, false);
+            const auto r13 = __builtin_amdgcn_permlane32_swap((uint32_t)W[1], (uint32_t)W[3], false, false);
+            const uint32_t v02 = r02[0] + r02[1];              // lower half: window candidate 0, upper half: 2
+            const uint32_t v13 = r13[0] + r13[1];              // lower half: 1, upper half: 3
+            const auto rq = __builtin_amdgcn_permlane16_swap(v02, v13, false, false);
+            uint32_t v = rq[0] + rq[1];                        // rows 0..3 of the wave: candidates 0..3
+            v += ms_dpp<MS_ROR8>(v);                           // |.| <= 2^30
+            long long t = (int)v;
+            t = ms_add_ror64<MS_ROR4>(t);
+            t = ms_add_ror64<MS_ROR2>(t);
+            t = ms_add_ror64<MS_ROR1>(t);                      // every lane of row c: the wave's sum of candidate c
+            if ((l & 15) == 0) rec->S[j0 + (l >> 4)] = t;
         } else {
         // transposed reduction: 24 -> 12 -> 6 -> 3 values per lane while summing over the lane
         // bits 5,4,3 (|partial| <= 2^30 stays in 32 bit), then three 64-bit steps inside the 8-lane
