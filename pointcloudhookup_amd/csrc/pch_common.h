@@ -113,6 +113,15 @@ int peek_wait(void* dst, size_t bytes);
 // xyz), 0, 0} - decoded in place by the grouping stage (segment_run, stats_encoded).  done: set by the run when the
 // table was filled (not on the per-chunk fallback for grids beyond the 64-bit key).
 struct DbBoxOut { uint32_t* acc; int32_t cap; bool done; };
+// stage B (pch_filter.hip): pch_ground_filter_f32's body.  early (optional): `bytes` device bytes at `dev` - they must
+// cover out_scalars, out_count and out_aabb - are queued for the host (peek_enqueue) directly behind the FIRST sweep and
+// its gf_finalize, i.e. in front of the launches of the fallback threshold, which return at once unless fewer than
+// min_keep rows survived.  The caller waits for that copy (peek_wait); if out_scalars[5] (fallback used) is set in
+// it, the values are not final yet and it queues and waits for a second copy, which then lies behind everything.
+struct GfEarly { const void* dev; size_t bytes; };
+int ground_filter_run(const float* raw, int64_t n, double pct, float offset, float fallback_offset, int64_t min_keep,
+                      float* out_points, int32_t* out_index, float* out_scalars, int64_t* out_count, float* out_aabb,
+                      void* ws, size_t ws_bytes, hipStream_t s, const GfEarly* early);
 // stage C with an early host copy of the cluster count (pch_dbscan.hip); k_host and box may be null
 int dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples, int64_t chunk_size,
                const float* aabb_host, int32_t* labels, uint8_t* core, int32_t* out_nclusters,

@@ -1,5 +1,6 @@
 // Library plumbing: version, thread-local error text, per-kernel hipEvent profiling.
 #include "pch_common.h"
+#include <chrono>
 
 #include <stdarg.h>
 #include <stdlib.h>
@@ -160,6 +161,20 @@ int peek_enqueue(const void* dev, size_t bytes, hipStream_t s) {
 }
 int peek_wait(void* dst, size_t bytes) {
     HostPeek& hp = host_peek();
+    // The GPU idles until the host has read these words and queued the next launches, so the host polls the event
+    // instead of sleeping on it (a blocking wait is woken tens of microseconds late) - for at most ~2 ms, the length
+    // of a whole step; behind that it blocks like anybody else (PCH_PEEK_BLOCK=1: block at once).
+    static const bool block = getenv("PCH_PEEK_BLOCK") != nullptr;
+    if (!block) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spin = 0;; ++spin) {
+            const hipError_t q = hipEventQuery(hp.ev);
+            if (q == hipSuccess) { memcpy(dst, hp.pinned, bytes); return PCH_OK; }
+            if (q != hipErrorNotReady) { PCH_HIP_TRY(q); }
+            if ((spin & 63) == 63 &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2000)) break;
+        }
+    }
     PCH_HIP_TRY(hipEventSynchronize(hp.ev));
     memcpy(dst, hp.pinned, bytes);
     return PCH_OK;

@@ -1296,7 +1296,14 @@ extern "C" int pch_ground_filter_f32(const float* raw, int64_t n, double pct, fl
                                      int32_t* out_index, float* out_scalars, int64_t* out_count,
                                      float* out_aabb, void* ws, size_t ws_bytes, void* stream) {
     PCH_DEVICE_GUARD(raw);
-    hipStream_t s = (hipStream_t)stream;
+    return pch::ground_filter_run(raw, n, pct, offset, fallback_offset, min_keep, out_points, out_index, out_scalars,
+                                  out_count, out_aabb, ws, ws_bytes, (hipStream_t)stream, nullptr);
+}
+
+int pch::ground_filter_run(const float* raw, int64_t n, double pct, float offset, float fallback_offset,
+                           int64_t min_keep, float* out_points, int32_t* out_index, float* out_scalars,
+                           int64_t* out_count, float* out_aabb, void* ws, size_t ws_bytes, hipStream_t s,
+                           const GfEarly* early) {
     PCH_REQUIRE(n >= 1 && n < (int64_t(1) << 31), "n out of range [1, 2^31) (numpy raises on empty input)");
     PCH_REQUIRE(raw && out_points && out_scalars && out_count && ws, "null buffer");
     PCH_REQUIRE(pct >= 0.0 && pct <= 100.0, "Percentiles must be in the range [0, 100]");
@@ -1338,21 +1345,29 @@ extern "C" int pch_ground_filter_f32(const float* raw, int64_t n, double pct, fl
     PCH_HIP_TRY(hipMemsetAsync(w.st, 0, w.clear_bytes, s));
     const dim3 grid((unsigned)nb), blk(GF_THREADS);
     const float* tcand = cand_made ? (const float*)w.cand.tcand : (const float*)nullptr;
-    if (cand_made) {
-        // from the candidate slots when the device-side guard allows it (gf_cand_ok); the sweeps over the tile below
-        // then return at once - and the other way round.  Same tiles, same tickets, same look-back words.
-        const int64_t nblk = ceil_div(n, GF_CBLK);
-        const dim3 cgrid((unsigned)ceil_div(nblk, GF_CT_BLKS));
+    // Sweep A (first threshold) from the candidate slots when the device-side guard allows it (gf_cand_ok), else over
+    // the tile - one of the two kernels returns at once; same tiles, same tickets, same look-back words.  Then the
+    // results are published ONCE ALREADY (gf_finalize; and queued for the host if the caller asked): they are final
+    // unless the last tile of sweep A raised use_b.  Sweep B (fallback threshold) and the second gf_finalize follow;
+    // without use_b they return at once, and the host is by then preparing the next stage.
+    const int64_t nblk = ceil_div(n, GF_CBLK);
+    const dim3 cgrid((unsigned)ceil_div(nblk, GF_CT_BLKS));
+    if (cand_made)
         PCH_LAUNCH("gf_cand", gf_cand_k<0>, cgrid, blk, 0, s, (const float*)w.cand.slots, (const uint32_t*)w.cand.counts,
                    tcand, nblk, (const float*)w.centroid, (const float*)w.sel.scal, w.st, w.status, (long long)min_keep,
                    out_points, out_index);
-        PCH_LAUNCH("gf_cand_fb", gf_cand_k<1>, cgrid, blk, 0, s, (const float*)w.cand.slots,
-                   (const uint32_t*)w.cand.counts, tcand, nblk, (const float*)w.centroid, (const float*)w.sel.scal, w.st,
-                   w.status + nb, (long long)min_keep, out_points, out_index);
-    }
     PCH_LAUNCH("gf_compact", gf_compact_k<0>, grid, blk, 0, s, raw, (const float*)w.zcol, n,
                (const float*)w.centroid, (const float*)w.sel.scal, w.st, w.status, (long long)min_keep, out_points,
                out_index, tcand);
+    if (early) {
+        PCH_LAUNCH("gf_finalize", gf_finalize_k, dim3(1), dim3(64), 0, s, (const GfState*)w.st,
+                   (const float*)w.centroid, (const float*)w.sel.scal, out_scalars, out_count, out_aabb);
+        PCH_TRY(peek_enqueue(early->dev, early->bytes, s));
+    }
+    if (cand_made)
+        PCH_LAUNCH("gf_cand_fb", gf_cand_k<1>, cgrid, blk, 0, s, (const float*)w.cand.slots,
+                   (const uint32_t*)w.cand.counts, tcand, nblk, (const float*)w.centroid, (const float*)w.sel.scal, w.st,
+                   w.status + nb, (long long)min_keep, out_points, out_index);
     PCH_LAUNCH("gf_compact_fb", gf_compact_k<1>, grid, blk, 0, s, raw, (const float*)w.zcol, n,
                (const float*)w.centroid, (const float*)w.sel.scal, w.st, w.status + nb, (long long)min_keep, out_points,
                out_index, tcand);

@@ -56,12 +56,18 @@ extern "C" int pch_tower_clusters_f32(const float* raw, int64_t n, double pct, f
     const size_t sub_bytes = ws_bytes - a.off;
 
     // ---- stage B
-    PCH_TRY(pch_ground_filter_f32(raw, n, pct, offset, fallback_offset, min_keep, out_points, out_index,
-                                  dev->scalars, &dev->count, dev->aabb, sub, sub_bytes, stream));
-    DevInfo h;
+    // the filter queues the copy of its results for the host directly behind its first sweep; the launches of the
+    // fallback threshold behind it return at once unless the fallback applies - the host is preparing stage C by then
     static_assert(sizeof(DevInfo) <= 256, "fits the pinned peek buffer");
-    PCH_TRY(peek_enqueue(dev, sizeof(DevInfo), s));
+    const GfEarly early = {dev, sizeof(DevInfo)};
+    PCH_TRY(ground_filter_run(raw, n, pct, offset, fallback_offset, min_keep, out_points, out_index,
+                              dev->scalars, &dev->count, dev->aabb, sub, sub_bytes, s, &early));
+    DevInfo h;
     PCH_TRY(peek_wait(&h, sizeof(DevInfo)));
+    if (h.scalars[5] != 0.0f && h.count >= 0) {          // the fallback threshold applies: the final values lie behind it
+        PCH_TRY(peek_enqueue(dev, sizeof(DevInfo), s));
+        PCH_TRY(peek_wait(&h, sizeof(DevInfo)));
+    }
     memcpy(info_host->centroid, h.scalars, 3 * sizeof(float));
     info_host->base = h.scalars[3];
     info_host->threshold = h.scalars[4];
