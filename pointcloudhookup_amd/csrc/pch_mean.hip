@@ -294,11 +294,17 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         for (int e = l; e < 3 * MSB; e += 64) tile[e] = e < 3 * cnt ? src[e] : 0.0f;   // ragged tail: zero padded
     }
     __builtin_amdgcn_wave_barrier();
+    // the block's z values, once: for the z column copy and for the candidate test below
+    float zr[MS_PER];
+    if (zcol || cslots) {
+#pragma unroll
+        for (int i = 0; i < MS_PER; ++i) zr[i] = tile[3 * (i * 64 + l) + 2];
+    }
     if (zcol) {
 #pragma unroll
         for (int i = 0; i < MS_PER; ++i) {
             const int p = i * 64 + l;
-            if (p < cnt) zcol[p0 + p] = tile[3 * p + 2];
+            if (p < cnt) zcol[p0 + p] = zr[i];
         }
     }
     if (cslots) {
@@ -307,12 +313,10 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         // exceed the estimate skips the sixteen rounds of ballots, ranks and plane stores (a quarter of this kernel's
         // vector instructions) for one wave maximum.
         const float tc = *tcand;
-        float zr[MS_PER];
         float zmax = -INFINITY;
 #pragma unroll
         for (int i = 0; i < MS_PER; ++i) {
             const int p = i * 64 + l;
-            zr[i] = tile[3 * p + 2];
             if (p < cnt) zmax = fmaxf(zmax, zr[i]);            // (NaN never exceeds anything: not a candidate either)
         }
         const bool some = __ballot(zmax > tc) != 0;
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
             // 16 roundings (relative 2^-20), which the factor and the + 1 cover (|absum| < 2^27)
             A0 = (int)ceilf(absum * 1.00001f) + 1;
         }
-        tie = ms_wave_all(tie & ((1u << MS_CAND) - 1u), [](uint32_t a, uint32_t b) { return a | b; });
+        if (__ballot(tie != 0u)) tie = ms_wave_all(tie & ((1u << MS_CAND) - 1u), [](uint32_t a, uint32_t b) { return a | b; });
         // ---- sparse ties (candidates >= MS_FIX_FROM with at most MS_FIX_MAX tie elements): every tie
         // leaves the running mantissa EVEN, and before it the parity is (incoming parity) ^ (parity of
         // the increments in front of it), which a few ballots give.  So the block's net increment is
