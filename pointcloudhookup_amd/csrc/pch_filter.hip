@@ -847,14 +847,15 @@ __global__ __launch_bounds__(GF_THREADS) void gf_compact_k(
     }
 }
 
-// The same sweep from the candidate slots: a workgroup takes 16 slots (16 384 rows of the tile, as gf_compact_k's
-// tile), a wave four of them.  ~10 % of the rows are candidates and they lie contiguously, so the sweep reads
-// ~16 B per candidate instead of the z column plus one memory line per survivor.
+// The same sweep from the candidate slots (MsCand, pch_mean.h: four planes per 1024-row block): a workgroup takes 64
+// slots, a wave 16 of them, round-major.  ~12 % of the rows are candidates and they lie contiguously, so the sweep
+// reads 4 B per candidate to count and 16 B per candidate for the rows, instead of the z column plus one memory
+// line per survivor.
 constexpr int GF_CBLK = 1024;                          // rows per block of the summary
 constexpr int GF_CSLOT = MS_CAND_SLOT;                 // candidate rows a slot holds
-constexpr int GF_CT_BLKS = 64;                         // slots per workgroup: 65 536 rows of the tile - large tiles because
-                                                       // the ticket word hands out only ~88 tiles per microsecond
-constexpr int GF_CW_BLKS = GF_CT_BLKS / (GF_THREADS / 64);     // 16 slots per wave, taken in groups of four
+constexpr int GF_CT_BLKS = 64;                         // slots per workgroup: 65 536 rows of the tile (32 measured no
+                                                       // faster; the ticket word hands out ~88 tiles per microsecond)
+constexpr int GF_CW_BLKS = GF_CT_BLKS / (GF_THREADS / 64);     // 16 slots per wave
 
 template <int WHICH>
 __global__ __launch_bounds__(GF_THREADS, 6) void gf_cand_k(     // six waves per SIMD: every tile of a 100 M-point call resident
