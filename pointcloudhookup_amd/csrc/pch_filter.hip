@@ -485,9 +485,13 @@ __global__ void sel_bracket_fix_k(BrState* __restrict__ br, SelRun* __restrict__
 // one launch in front of a select: clears the histograms (and the bracket state), sets the ranks of up to 3 runs
 __global__ __launch_bounds__(256) void selx_init_k(uint32_t* __restrict__ hist, int nwords, SelRun* __restrict__ runs,
                                                    int nruns, unsigned long long r0, unsigned long long r1,
-                                                   unsigned long long r2, BrState* __restrict__ br) {
+                                                   unsigned long long r2, BrState* __restrict__ br,
+                                                   uint32_t* __restrict__ also_zero, int64_t also_words) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < nwords) hist[i] = 0;
+    // words of the caller that must be zero before a LATER kernel of the same call (the fused filter's sweep state and
+    // look-back words: a fill of their own sat on the critical path between the interpolation and the sweep)
+    for (int64_t j = i; j < also_words; j += (int64_t)gridDim.x * 256) also_zero[j] = 0u;
     if (i < nruns) {
         SelRun z;
         memset(&z, 0, sizeof(z));
@@ -509,6 +513,8 @@ struct SelWs {
     float    *sample, *cand;
     int64_t   ns;       // sample size
     uint32_t  cap;      // candidate capacity
+    uint32_t* also_zero;   // optional: words sel_init clears for the caller (see selx_init_k)
+    int64_t   also_words;
 };
 static void sel_plan(Arena& a, SelWs& w, int64_t n = 0) {
     w.st = a.take<SelState>(1);
@@ -517,6 +523,7 @@ static void sel_plan(Arena& a, SelWs& w, int64_t n = 0) {
     w.run = a.take<SelRun>(3);
     w.xhist = a.take<uint32_t>(9 * SEL_BINS);
     w.br = nullptr; w.sample = w.cand = nullptr; w.ns = 0; w.cap = 0;
+    w.also_zero = nullptr; w.also_words = 0;
     if (n >= SEL_BRACKET_MIN) {
         w.br = a.take<BrState>(1);
         w.ns = SEL_GROUP * (n / SEL_EVERY);
@@ -586,7 +593,8 @@ static int select_sample_passes(const float* src, int64_t src_stride, int64_t n,
     const SelBracket br = select_bracket_ranks(w, n, pi);
     const int64_t ns = w.ns;
     PCH_LAUNCH("sel_init", selx_init_k, dim3((unsigned)ceil_div(9 * SEL_BINS, 256)), dim3(256), 0, s, w.xhist,
-               9 * SEL_BINS, w.run, 3, (unsigned long long)br.r_lo, (unsigned long long)br.r_hi, 0ull, w.br);
+               9 * SEL_BINS, w.run, 3, (unsigned long long)br.r_lo, (unsigned long long)br.r_hi, 0ull, w.br,
+               w.also_zero, w.also_words);
     PCH_LAUNCH("sel_sample", sel_sample_k, dim3((unsigned)ceil_div(ns, 1024)), dim3(256), 0, s, src, src_stride, ns,
                w.sample);
     int64_t gs = ceil_div(ns, SEL_TILE);                   // both ends of the bracket in the same three sweeps
@@ -609,7 +617,8 @@ static int select_passes(const float* base, int64_t n, int64_t stride, double q_
     uint32_t* hfin = w.xhist + 6 * SEL_BINS;
     if (!select_is_bracketed(w, n, stride)) {
         PCH_LAUNCH("sel_init", selx_init_k, dim3((unsigned)ceil_div(9 * SEL_BINS, 256)), dim3(256), 0, s, w.xhist,
-                   9 * SEL_BINS, w.run, 3, 0ull, 0ull, (unsigned long long)pi.k0, (BrState*)nullptr);
+                   9 * SEL_BINS, w.run, 3, 0ull, 0ull, (unsigned long long)pi.k0, (BrState*)nullptr, w.also_zero,
+                   w.also_words);
         return select_rounds(base, n, stride, !pi.same, fin, hfin, s, always, n);
     }
     if (!sample_done) PCH_TRY(select_sample_passes(base, 1, n, q_percent, w, s));
@@ -1318,6 +1327,9 @@ int pch::ground_filter_run(const float* raw, int64_t n, double pct, float offset
     w.cand.pct = pct;
     w.cand.add = (offset < fallback_offset ? offset : fallback_offset) - 0.5f;
     bool cand_made = false;
+    // the sweep's state and look-back words are cleared by the select's init kernel (first thing on the side stream)
+    w.sel.also_zero = reinterpret_cast<uint32_t*>(w.st);
+    w.sel.also_words = (int64_t)(w.clear_bytes / 4);
     SideStream& ss = side_stream();
     if (ss.ok) {
         // Two strands.  `s`: summary, level 2, walk - no cross-stream hop inside the chain.  Side stream: at once the
@@ -1343,7 +1355,6 @@ int pch::ground_filter_run(const float* raw, int64_t n, double pct, float offset
         PCH_TRY(select_passes(w.zcol, n, 1, pct, w.sel, s));
     }
     PCH_TRY(select_lerp(n, w.centroid + 2, pct, offset, fallback_offset, w.sel, s));
-    PCH_HIP_TRY(hipMemsetAsync(w.st, 0, w.clear_bytes, s));
     const dim3 grid((unsigned)nb), blk(GF_THREADS);
     const float* tcand = cand_made ? (const float*)w.cand.tcand : (const float*)nullptr;
     // Sweep A (first threshold) from the candidate slots when the device-side guard allows it (gf_cand_ok), else over
