@@ -169,12 +169,19 @@ int peek_wait(void* dst, size_t bytes) {
         const auto t0 = std::chrono::steady_clock::now();
         for (int spin = 0;; ++spin) {
             const hipError_t q = hipEventQuery(hp.ev);
-            if (q == hipSuccess) { memcpy(dst, hp.pinned, bytes); return PCH_OK; }
+            if (q == hipSuccess) {
+                // "not ready" is an answer, not a failure: it must not be what the next launch's hipGetLastError()
+                // check finds (whether the runtime latches it has differed between releases)
+                if (spin) (void)hipGetLastError();
+                memcpy(dst, hp.pinned, bytes);
+                return PCH_OK;
+            }
             if (q != hipErrorNotReady) { PCH_HIP_TRY(q); }
             if ((spin & 63) == 63 &&
                 std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2000)) break;
         }
     }
+    if (!block) (void)hipGetLastError();                  // (see above: the polls before this answered "not ready")
     PCH_HIP_TRY(hipEventSynchronize(hp.ev));
     memcpy(dst, hp.pinned, bytes);
     return PCH_OK;
