@@ -763,7 +763,7 @@ __global__ __launch_bounds__(GF_THREADS) void gf_compact_k(
 #pragma unroll 8
     for (int r = 0; r < GF_ROUNDS; ++r) {
         const int64_t i = seg + r * 64 + l;
-        const float z = i < n ? zcol[i] : 0.0f;
+        const float z = i < n ? (zcol ? zcol[i] : raw[3 * i + 2]) : 0.0f;     // no column given: the z of the rows
         const bool keep = i < n && (z - cz) > thr;       // points = raw_points - centroid (float32)
         const unsigned long long m = __ballot(keep);
         if (l == 0) masks[w][r] = m;
@@ -1240,17 +1240,12 @@ extern "C" size_t pch_filter_gt_ws_bytes(int64_t n) {
     if (n < 0) return 0;
     Arena a;
     a.take<float>(8);
-    a.take<float>(n > 0 ? n : 1);
     a.take<GfState>(1);
     a.take<uint64_t>(2 * ceil_div(n > 0 ? n : 1, GF_TILE));
     return a.off;
 }
 
 namespace pch {
-__global__ void gf_zcol_k(const float* __restrict__ raw, int64_t n, float* __restrict__ zcol) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) zcol[i] = raw[3 * i + 2];
-}
 __global__ void gf_count_out_k(const GfState* __restrict__ st, int64_t* __restrict__ out_count, float* __restrict__ out_aabb) {
     if (threadIdx.x == 0) *out_count = st->failed ? (int64_t)-1 : (int64_t)st->total[0];
     if (threadIdx.x < 6 && out_aabb) {
@@ -1275,7 +1270,6 @@ extern "C" int pch_filter_gt_f32(const float* raw, int64_t n, const float* centr
     PCH_REQUIRE(raw && out_points, "null buffer");
     Arena a(ws, ws_bytes);
     float* scal = a.take<float>(8);                  // [0..2] centroid, [5] threshold (gf_compact_k<0> reads scal[4 + 1])
-    float* zcol = a.take<float>(n);
     const size_t st_off = a.off;
     GfState* st = a.take<GfState>(1);
     const int64_t nb = ceil_div(n, GF_TILE);
@@ -1284,8 +1278,9 @@ extern "C" int pch_filter_gt_f32(const float* raw, int64_t n, const float* centr
     float hs[8] = {centroid3_host[0], centroid3_host[1], centroid3_host[2], 0.0f, 0.0f, threshold, threshold, 0.0f};
     PCH_HIP_TRY(hipMemcpyAsync(scal, hs, sizeof(hs), hipMemcpyHostToDevice, s));
     PCH_HIP_TRY(hipMemsetAsync(st, 0, a.off - st_off, s));
-    PCH_LAUNCH("gf_zcol", gf_zcol_k, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, raw, n, zcol);
-    PCH_LAUNCH("gf_compact", gf_compact_k<0>, dim3((unsigned)nb), dim3(GF_THREADS), 0, s, raw, (const float*)zcol, n,
+    // the sweep reads z straight from the rows (a pass that first copied the z column out - 16 B per point of traffic
+    // for a 12 B per point sweep - is gone)
+    PCH_LAUNCH("gf_compact", gf_compact_k<0>, dim3((unsigned)nb), dim3(GF_THREADS), 0, s, raw, (const float*)nullptr, n,
                (const float*)scal, (const float*)(scal + 4), st, status, (long long)0, out_points, out_index,
                (const float*)nullptr);
     PCH_LAUNCH("gf_count_out", gf_count_out_k, dim3(1), dim3(64), 0, s, (const GfState*)st, out_count, out_aabb);
