@@ -68,7 +68,11 @@ int         pch_device_count(void);
  *            min(chunk) - voxel/2; duplicates across chunks are kept (as the reference).
  * out_idx    [n,3] int32   voxel index triplets   } capacity n rows, the first *out_m rows
  * out_mean   [n,3] float64 sum(points in order)/count } are valid; rows are grouped by chunk
- * out_count  [n]   int32                           } and sorted by (ix,iy,iz) inside a chunk
+ * out_count  [n]   int32                           } (order inside a chunk: see below)
+ * Order inside a chunk: Open3D emits unordered_map iteration order, i.e. unspecified; parity is the SET of
+ * (index, mean, count) per chunk.  This library emits coarse grid cells (the top bits of [ix|iy|iz]) in ascending
+ * order and, inside a cell, the voxels in the order of their first points - or sorted by (ix,iy,iz) where a cell
+ * takes the sorting path (dense cells, wide keys).  Deterministic for a given input.
  * out_chunk_offsets [nchunks+1] int64 (may be NULL): slice of each chunk in the output
  * out_m      [1] int64 number of voxels
  */
@@ -342,9 +346,9 @@ size_t pch_crop_aabb_ws_bytes(int64_t n);
 int pch_crop_aabb_f64(const double* xyz, int64_t n, const double* min3_host, const double* max3_host,
                       double* out_points, int64_t* out_index, int64_t* out_count,
                       void* ws, size_t ws_bytes, void* stream);
-/* Self-test of the bounded wait: launches four look-back tiles of which one never publishes and returns
- * PCH_ERR_TIMEOUT when the tiles behind it gave up within budget_ms (1..2000) as designed; PCH_ERR_HIP when they did
- * not.  dev_scratch: >= 256 bytes of device memory.  Synchronises.  Not part of the data path (tests only). */
+/* Self-test of the bounded wait: launches eight look-back tiles of which the second never publishes and returns
+ * PCH_ERR_TIMEOUT when the six tiles behind it gave up within budget_ms (1..2000) as designed AND the count word they
+ * marked (sign bit, as the data-path kernels mark theirs) reads negative; PCH_ERR_HIP when not.  dev_scratch: >= 256 bytes of device memory.  Synchronises.  Not part of the data path (tests only). */
 int pch_selftest_lookback_timeout(int budget_ms, void* dev_scratch, size_t scratch_bytes, void* stream);
 
 /* Preview decimation: k distinct rows chosen by a seeded pseudo-random bijection of the row range.

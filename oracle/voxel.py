@@ -13,8 +13,9 @@ unpinned version):
 
 Open3D emits voxels in ``std::unordered_map`` iteration order, which is
 platform defined; parity is therefore defined on the *set* of
-(voxel index, mean, count) triples.  This oracle and the HIP path both emit
-voxels sorted by (ix, iy, iz).
+(voxel index, mean, count) triples per chunk.  This oracle emits the voxels of a
+chunk sorted by (ix, iy, iz); the HIP path emits them grouped by chunk in an order
+of its own (``canonical`` below sorts any output the oracle's way for comparison).
 """
 from __future__ import annotations
 
@@ -82,6 +83,25 @@ def voxel_down_sample_chunked(points, voxel_size, chunk_size):
                 np.zeros((1,), np.int64))
     return (np.vstack(idxs), np.vstack(means), np.concatenate(counts),
             np.asarray(offs, dtype=np.int64))
+
+
+def canonical(idx, mean, count, chunk_offsets):
+    """(idx, mean, count) with every chunk's voxels sorted by (ix, iy, iz) - the order this oracle emits.
+    Parity of stage A is set equality per chunk: comparing canonical forms is exactly that,
+    provided no voxel index repeats inside a chunk (checked)."""
+    idx = np.asarray(idx)
+    mean = np.asarray(mean)
+    count = np.asarray(count)
+    offs = np.asarray(chunk_offsets, dtype=np.int64)
+    order = np.empty(len(count), dtype=np.int64)
+    for c in range(len(offs) - 1):
+        a, b = int(offs[c]), int(offs[c + 1])
+        o = np.lexsort((idx[a:b, 2], idx[a:b, 1], idx[a:b, 0]))
+        order[a:b] = a + o
+        si = idx[a:b][o]
+        if len(si) > 1:
+            assert np.any(si[1:] != si[:-1], axis=1).all(), "a voxel index repeats inside a chunk"
+    return idx[order], mean[order], count[order]
 
 
 def las_scaled(X, scale, offset):

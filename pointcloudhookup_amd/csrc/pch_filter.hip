@@ -718,8 +718,9 @@ struct GfState {
 
 // ---- the candidate rows of the summary pass (MsCand, pch_mean.h) -------------------------------------------------
 // May the sweep read the candidate slots instead of the tile?  Only if no survivor can be missing from them.  A row
-// survives iff fl(z - cz) > thr; the slots hold every row with z > tcand.  If tcand <= thr + cz (as real numbers: both
-// sums are exact in double), a row with z <= tcand has z - cz <= thr, and rounding is monotone with fl(thr) = thr, so
+// survives iff fl(z - cz) > thr; the slots hold every row with z > tcand.  If tcand <= thr + cz (as real numbers: the
+// double sum is exact while the two exponents are within 29 bits, and the test takes one step below it for when they
+// are not), a row with z <= tcand has z - cz <= thr, and rounding is monotone with fl(thr) = thr, so
 // fl(z - cz) <= thr: it does not survive.  The same test, on the same device words, decides in gf_cand_k (go) and in
 // gf_compact_k (stand down), for both thresholds at once; a NaN anywhere fails it.
 __device__ __forceinline__ bool gf_cand_ok(const float* __restrict__ tcand, const float* __restrict__ centroid,
@@ -729,7 +730,9 @@ __device__ __forceinline__ bool gf_cand_ok(const float* __restrict__ tcand, cons
     const double cz = (double)centroid[2];
     const double ta = (double)scal[1] + cz, tb = (double)scal[2] + cz;
     const double t = (double)*tcand;
-    return t <= ta && t <= tb;
+    // the two sums are exact in double unless the exponents of threshold and centroid lie more than 29 bits apart;
+    // one step below the (then rounded) sum is at or below the real sum either way
+    return t <= nextafter(ta, -INFINITY) && t <= nextafter(tb, -INFINITY);
 }
 
 template <int WHICH>
@@ -1332,8 +1335,8 @@ int pch::ground_filter_run(const float* raw, int64_t n, double pct, float offset
         // runs beside the summary), then - behind the summary - the percentile's sweep and exact select; joined in
         // front of the interpolation.  With the sample half out of the way both strands end within a few us of each
         // other (measured: the other assignment, select on `s` and walk on the side stream, loses 45 us to the hops).
-        const bool early = select_is_bracketed(w.sel, n, 1);
-        if (early) {
+        const bool sample_early = select_is_bracketed(w.sel, n, 1);
+        if (sample_early) {
             PCH_HIP_TRY(hipEventRecord(ss.ev_start, s));            // everything the caller queued before this call
             PCH_HIP_TRY(hipStreamWaitEvent(ss.s, ss.ev_start, 0));   // (the rows; the previous user of the workspace)
             PCH_TRY(select_sample_passes(raw + 2, 3, n, pct, w.sel, ss.s));
@@ -1341,7 +1344,7 @@ int pch::ground_filter_run(const float* raw, int64_t n, double pct, float offset
         PCH_TRY(mean_seq_launch(raw, n, w.centroid, w.ms, w.zcol, s, ss.ev_fork, nullptr, MS_DIVIDE_BY_N, MS_PHASE_BOTH,
                                 &w.cand, &cand_made));
         PCH_HIP_TRY(hipStreamWaitEvent(ss.s, ss.ev_fork, 0));
-        PCH_TRY(select_passes(w.zcol, n, 1, pct, w.sel, ss.s, early));
+        PCH_TRY(select_passes(w.zcol, n, 1, pct, w.sel, ss.s, sample_early));
         PCH_HIP_TRY(hipEventRecord(ss.ev_join, ss.s));
         PCH_HIP_TRY(hipStreamWaitEvent(s, ss.ev_join, 0));
     } else {

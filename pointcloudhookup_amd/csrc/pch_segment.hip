@@ -216,9 +216,12 @@ __global__ __launch_bounds__(SG_THREADS) void sl_scatter_k(const int32_t* __rest
 // offsets[k] = start of bin k = scanned count of (bin k, tile 0); offsets[K] = start of the noise rows
 __global__ __launch_bounds__(SG_THREADS) void sl_offsets_k(const uint32_t* __restrict__ offs, int64_t nb,
                                                            int32_t nclusters, int64_t* __restrict__ offsets,
-                                                           uint32_t* enc_stats) {
+                                                           uint32_t* enc_stats, const uint32_t* __restrict__ scan_total) {
     const int k = blockIdx.x * SG_THREADS + threadIdx.x;
-    if (k <= nclusters) offsets[k] = (int64_t)offs[(int64_t)k * nb];
+    // a single-pass scan whose bounded look-back wait gave up (pch_lookback.h) raised its total word to 0xFFFFFFFF:
+    // perm and offsets are then undefined, and every offset reads -1 (include/pch_hip.h, PCH_ERR_TIMEOUT)
+    const bool failed = scan_total && *scan_total == 0xFFFFFFFFu;
+    if (k <= nclusters) offsets[k] = failed ? int64_t(-1) : (int64_t)offs[(int64_t)k * nb];
     if (enc_stats && k < 8 * nclusters) sg_decode_word(enc_stats, k);
 }
 
@@ -303,14 +306,17 @@ int pch::segment_run(const int32_t* labels, const float* xyz, int64_t n, int32_t
         PCH_REQUIRE(zero_words <= nb * SG_THREADS, "count table too large for the fused zeroing");   // (K+1)/1024 < 256
         PCH_LAUNCH("seg_hist", sl_hist_k, dim3((unsigned)nb), dim3(SG_THREADS), 0, s, labels, n, nclusters,
                    w.table, nb, w.table_scan, zero_words);
-        if (one) PCH_TRY(scan1_exclusive_u32(w.table, w.table, table, w.table_scan, nullptr, s));
+        // the single-pass scan reports a look-back time-out through its total word: the spare word behind the ticket
+        // (scan1_ws_u32 rounds 2 * tiles + 1 up), zeroed with the rest of the scratch by sl_hist_k
+        const uint32_t* scan_total = one ? w.table_scan + 2 * ceil_div(table, (int64_t)SCAN_TILE) + 1 : nullptr;
+        if (one) PCH_TRY(scan1_exclusive_u32(w.table, w.table, table, w.table_scan, const_cast<uint32_t*>(scan_total), s));
         else PCH_TRY(scan_exclusive_u32(w.table, w.table, table, w.table_scan, nullptr, s));
         PCH_LAUNCH("seg_scatter", sl_scatter_k, dim3((unsigned)nb), dim3(SG_THREADS), 0, s, labels, n, nclusters,
                    (const uint32_t*)w.table, nb, out_perm);
         PCH_LAUNCH("seg_offsets", sl_offsets_k,
                    dim3((unsigned)ceil_div(stats_encoded ? 8 * (int64_t)nclusters + 1 : (int64_t)nclusters + 1, SG_THREADS)),
                    dim3(SG_THREADS), 0, s, (const uint32_t*)w.table, nb, nclusters, out_offsets,
-                   stats_encoded ? reinterpret_cast<uint32_t*>(out_stats) : (uint32_t*)nullptr);
+                   stats_encoded ? reinterpret_cast<uint32_t*>(out_stats) : (uint32_t*)nullptr, scan_total);
     } else {
         PCH_LAUNCH("seg_keys", sg_keys_k, dim3(gn), dim3(SG_THREADS), 0, s, labels, n, nclusters, w.k0, w.v0);
         const int nbits = bits_for((uint64_t)nclusters + 1);

@@ -57,10 +57,11 @@ __global__ __launch_bounds__(CR_THREADS) void crop_aabb_k(const double* __restri
         const uint32_t e = lb_failed ? 0u : e0;              // prefix 0 keeps the writes below inside the output
         if (l == 0) {
             excl_sh = e;
-            // out_count starts at 0: the last tile adds the total, a tile whose wait ran out of its budget adds
-            // -2^62 - the sum is negative iff some tile failed, in whatever order the two happen
+            // out_count starts at 0: the last tile adds the total (< 2^62), a tile whose wait ran out of its budget
+            // sets the sign bit - idempotent, so the word reads negative iff some tile failed, however many did
+            // (every tile behind a poisoned one fails too) and in whatever order the two happen
             unsigned long long* oc = reinterpret_cast<unsigned long long*>(out_count);
-            if (lb_failed) atomicAdd(oc, (unsigned long long)(-(1ll << 62)));
+            if (lb_failed) atomicOr(oc, 1ull << 63);
             else if (tile == (int64_t)gridDim.x - 1) atomicAdd(oc, (unsigned long long)e + T);
         }
     }
@@ -150,12 +151,14 @@ extern "C" int pch_crop_aabb_f64(const double* xyz, int64_t n, const double* min
     return PCH_OK;
 }
 
-// ---- self-test of the bounded look-back wait (pch_lookback.h): four tiles in ticket order, the workgroup that
+// ---- self-test of the bounded look-back wait (pch_lookback.h): eight tiles in ticket order, the workgroup that
 // draws ticket 1 leaves WITHOUT publishing - what a lost or never-scheduled tile looks like to the tiles behind
-// it.  Tickets 2 and 3 must give up after `budget` ticks, poison their words and raise the failure word; the grid
-// drains by construction.  Never part of the data path.
+// it.  Tickets 2..7 must give up after `budget` ticks (the first by its own clock, the rest on its poisoned word),
+// poison their words and mark the count word exactly like crop_aabb_k / vx_finish_k do (sign bit, idempotent;
+// the last ticket would add the total); the grid drains by construction.  Never part of the data path.
 namespace pch {
 __global__ __launch_bounds__(64) void lb_selftest_k(uint64_t* __restrict__ status, uint32_t* __restrict__ state,
+                                                    unsigned long long* __restrict__ count,
                                                     unsigned long long budget) {
     __shared__ uint32_t tile_sh;
     if (threadIdx.x == 0) tile_sh = atomicAdd(&state[0], 1u);
@@ -164,8 +167,11 @@ __global__ __launch_bounds__(64) void lb_selftest_k(uint64_t* __restrict__ statu
     if (tile == 1) return;                               // the tile that never publishes
     const uint32_t e = gf_lookback(status, tile, 1u, false, budget);
     if (threadIdx.x == 0) {
-        if (e == GF_LB_FAILED) atomicAdd(&state[1], 1u);
-        else atomicAdd(&state[2], 1u);
+        if (e == GF_LB_FAILED) { atomicAdd(&state[1], 1u); atomicOr(count, 1ull << 63); }
+        else {
+            atomicAdd(&state[2], 1u);
+            if (tile == (int64_t)gridDim.x - 1) atomicAdd(count, (unsigned long long)e + 1u);
+        }
     }
 }
 }  // namespace pch
@@ -175,15 +181,22 @@ extern "C" int pch_selftest_lookback_timeout(int budget_ms, void* dev_scratch, s
     hipStream_t s = (hipStream_t)stream;
     PCH_REQUIRE(budget_ms >= 1 && budget_ms <= 2000 && dev_scratch && scratch_bytes >= 256, "bad argument");
     uint64_t* status = static_cast<uint64_t*>(dev_scratch);
-    uint32_t* state = reinterpret_cast<uint32_t*>(status + 8);
+    uint32_t* state = reinterpret_cast<uint32_t*>(status + 8);                 // 8 status words, then 4 state words,
+    unsigned long long* count = reinterpret_cast<unsigned long long*>(status + 10);   // then the published count word
     PCH_HIP_TRY(hipMemsetAsync(dev_scratch, 0, 256, s));
-    PCH_LAUNCH("lb_selftest", lb_selftest_k, dim3(4), dim3(64), 0, s, status, state,
+    PCH_LAUNCH("lb_selftest", lb_selftest_k, dim3(8), dim3(64), 0, s, status, state, count,
                (unsigned long long)budget_ms * 100000ull);
-    uint32_t st[4];
+    uint32_t st[6];                                      // state[0..3] + the 64-bit count word
     PCH_TRY(peek_enqueue(state, sizeof(st), s));
     PCH_TRY(peek_wait(st, sizeof(st)));
-    if (st[0] != 4 || st[1] != 2 || st[2] != 1) {        // ticket 0 succeeds, 1 leaves, 2 and 3 give up
-        set_error("look-back self-test: tickets %u, gave up %u, succeeded %u (expected 4 / 2 / 1)", st[0], st[1], st[2]);
+    long long published;
+    memcpy(&published, &st[4], sizeof(published));
+    if (st[0] != 8 || st[1] != 6 || st[2] != 1) {       // ticket 0 succeeds, 1 leaves, 2..7 give up
+        set_error("look-back self-test: tickets %u, gave up %u, succeeded %u (expected 8 / 6 / 1)", st[0], st[1], st[2]);
+        return PCH_ERR_HIP;
+    }
+    if (published >= 0) {                                // six failure marks must still read as a failure
+        set_error("look-back self-test: the count word reads %lld after six failed tiles (must be negative)", published);
         return PCH_ERR_HIP;
     }
     set_error("look-back wait ran out of its %d ms budget (self-test: expected)", budget_ms);

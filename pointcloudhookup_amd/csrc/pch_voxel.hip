@@ -434,18 +434,28 @@ __global__ __launch_bounds__(VP_THREADS) void vx_scatter_k(const double* __restr
 // One batch per workgroup iteration.  LDS sort: what is sorted is a 32-bit key
 //   ((level-1 digit - first digit of the batch) << rem) | (low `rem` bits of the voxel key)
 // together with the row's position in the batch (uint16); the rows themselves stay in L2.
+constexpr uint32_t VQ_SLOTS = 2 * VF_CAP;            // hash-set slots of a batch (load factor <= 1/2)
+constexpr uint32_t VQ_MAXRUN = 32;                   // rows per voxel the grouping path takes (else: the stable sort)
 struct VfShared {
     union {
         struct {
-            uint32_t key[2][VF_CAP];             // 64 KB
-            uint16_t perm[2][VF_CAP];            // 32 KB
+            uint32_t key[2][VF_CAP];             // 32 KB (key[0..1] together: the hash set of both LDS paths)
+            uint16_t perm[2][VF_CAP];            // 16 KB
         };
+        struct {                                 // grouping path (vf_group): hash set, per-slot row counts (one BYTE
+            uint32_t hset[VQ_SLOTS];             // per slot, four to a word), first position of every slot's rows,
+            uint32_t hcnt[VQ_SLOTS / 4];         // the rows' positions grouped by slot, and one bit per position that
+            uint16_t sstart[VQ_SLOTS];           // is the first row of its voxel
+            uint16_t pos[VF_CAP];
+            unsigned long long headbits[VF_CAP / 64];
+            uint32_t headpre[VF_CAP / 64];
+        } q;
         uint32_t hist[8][256];                   // general path: digit histograms of every LSD pass
     };
     uint32_t cnt[VF_WAVES][256];                 // per-wave digit counters / offsets (16 KB)
     uint32_t base[256];
     uint32_t wsum[VF_WAVES];
-    uint32_t ticket, vbase, lb_failed;
+    uint32_t ticket, vbase, lb_failed, overflow;
 };
 
 // block-wide exclusive scan of one value per thread (VF_THREADS threads); total returned to all
@@ -529,8 +539,125 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
         const uint32_t* srt = nullptr;                     // LDS path: sorted keys / their rows / voxel starts
         const uint16_t* sperm = nullptr;
         const uint32_t* vst = nullptr;
-        if (R == 0) {
-            // a reserved slot that was not needed: publishes zero voxels below
+        // ---------------- grouping path: rows grouped by HASH SLOT, not sorted by key ----------------
+        // The exact hash set that counts the batch's voxels already says which rows belong together; what Open3D's
+        // accumulation needs on top is the FILE ORDER inside a voxel, not an order between voxels (its own output
+        // order is unordered_map iteration order).  So: every row takes a ticket on its slot's counter (arrival
+        // order, arbitrary), the slots' counts are scanned, the rows' positions are scattered to their slot's run, and
+        // the thread of the row that arrived FIRST sorts that run (1-3 positions as a rule) and adds the rows in
+        // ascending position = file order.  Voxels leave the batch in the order of their first rows (a bit per
+        // position + prefix popcounts): deterministic, whatever the arrival order was.  One pass over the rows for
+        // the keys, no radix pass at all (the stable LDS sort below costs 3-4 passes of a ballot per key bit).
+        // A batch with a voxel of more than VQ_MAXRUN rows takes the stable sort below instead.
+        bool grouped = false, skip_early = false;
+        uint32_t gkey[VP_ROUNDS], ghs[VP_ROUNDS];           // grouping path: relative key; slot | arrival ticket << 16
+        if (R != 0 && !selecting && R <= (uint32_t)VF_CAP && sortbits <= 31) {
+            for (uint32_t j = tid; j < VQ_SLOTS; j += VF_THREADS) sh.q.hset[j] = 0xFFFFFFFFu;
+            for (uint32_t j = tid; j < VQ_SLOTS / 4; j += VF_THREADS) sh.q.hcnt[j] = 0u;
+            if (tid < VF_CAP / 64) sh.q.headbits[tid] = 0ull;
+            if (tid == 0) sh.overflow = 0u;
+            __syncthreads();
+            uint32_t* const kreg = gkey;
+            uint32_t* const hs = ghs;
+            uint32_t fresh = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                   // four rows per thread in flight
+                Row q[VP_ROUNDS / 2];
+#pragma unroll
+                for (int r = 0; r < VP_ROUNDS / 2; ++r) {
+                    const uint32_t i = (h * (VP_ROUNDS / 2) + r) * VF_THREADS + tid;
+                    q[r] = bufA[s + (i < R ? i : 0)];
+                }
+#pragma unroll
+                for (int r = 0; r < VP_ROUNDS / 2; ++r) {
+                    const int rr = h * (VP_ROUNDS / 2) + r;
+                    const uint32_t i = rr * VF_THREADS + tid;
+                    const uint64_t k = vx_key(g, mb, q[r]);
+                    kreg[rr] = (uint32_t)((((k >> g.rem) - d0) << g.rem) | (k & remmask));
+                    hs[rr] = 0xFFFFFFFFu;
+                    if (i < R) {
+                        uint32_t slot = (kreg[rr] * 2654435761u) >> (32 - 13);
+                        static_assert(VQ_SLOTS == (1u << 13), "slot bits");
+                        for (;;) {
+                            const uint32_t old = atomicCAS(&sh.q.hset[slot], 0xFFFFFFFFu, kreg[rr]);
+                            if (old == 0xFFFFFFFFu) { ++fresh; break; }
+                            if (old == kreg[rr]) break;
+                            slot = (slot + 1) & (VQ_SLOTS - 1);
+                        }
+                        const uint32_t sft = (slot & 3u) * 8u;
+                        const uint32_t tk = (atomicAdd(&sh.q.hcnt[slot >> 2], 1u << sft) >> sft) & 255u;
+                        // a byte counter spills into its neighbour at 256 - long after some row has seen a ticket
+                        // >= VQ_MAXRUN and sent the whole batch to the stable sort
+                        if (tk >= VQ_MAXRUN) sh.overflow = 1u;
+                        hs[rr] = slot | (tk << 16);
+                    }
+                }
+            }
+            {
+                uint32_t tot;
+                vf_block_scan(fresh, sh.wsum, tot);        // (its barriers also publish the counters and the flag)
+                if (tid == 0) gf_announce(status, (int64_t)t, tot);
+                nvox = tot;
+            }
+            announced = true;
+            if (sh.overflow == 0u) {
+                grouped = true;
+                // ---- exclusive scan of the slots' counts: 16 slots (16 count bytes) per thread
+                {
+                    const uint4 c4 = reinterpret_cast<const uint4*>(sh.q.hcnt)[tid];
+                    const uint32_t cw[4] = {c4.x, c4.y, c4.z, c4.w};
+                    uint32_t pre[16], run = 0;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { pre[j] = run; run += (cw[j >> 2] >> (8 * (j & 3))) & 255u; }
+                    uint32_t tot;
+                    const uint32_t ex = vf_block_scan(run, sh.wsum, tot);
+                    uint4 o0, o1;
+                    o0.x = (ex + pre[0]) | ((ex + pre[1]) << 16);   o0.y = (ex + pre[2]) | ((ex + pre[3]) << 16);
+                    o0.z = (ex + pre[4]) | ((ex + pre[5]) << 16);   o0.w = (ex + pre[6]) | ((ex + pre[7]) << 16);
+                    o1.x = (ex + pre[8]) | ((ex + pre[9]) << 16);   o1.y = (ex + pre[10]) | ((ex + pre[11]) << 16);
+                    o1.z = (ex + pre[12]) | ((ex + pre[13]) << 16); o1.w = (ex + pre[14]) | ((ex + pre[15]) << 16);
+                    reinterpret_cast<uint4*>(sh.q.sstart)[2 * tid] = o0;
+                    reinterpret_cast<uint4*>(sh.q.sstart)[2 * tid + 1] = o1;
+                }
+                __syncthreads();
+                // ---- positions to their slot's run (arrival order)
+#pragma unroll
+                for (int r = 0; r < VP_ROUNDS; ++r)
+                    if (hs[r] != 0xFFFFFFFFu)
+                        sh.q.pos[sh.q.sstart[hs[r] & 0xFFFFu] + (hs[r] >> 16)] = (uint16_t)(r * VF_THREADS + tid);
+                __syncthreads();
+                // ---- the row that arrived first owns its voxel: sorts the run, marks the voxel's first position
+#pragma unroll
+                for (int r = 0; r < VP_ROUNDS; ++r) {
+                    if (hs[r] != 0xFFFFFFFFu && (hs[r] >> 16) == 0u) {
+                        const uint32_t slot = hs[r] & 0xFFFFu;
+                        const uint32_t a0 = sh.q.sstart[slot];
+                        const uint32_t cn = (sh.q.hcnt[slot >> 2] >> (8 * (slot & 3u))) & 255u;
+                        for (uint32_t a = 1; a < cn; ++a) {             // insertion sort, ascending positions
+                            const uint16_t v = sh.q.pos[a0 + a];
+                            uint32_t b = a;
+                            while (b > 0 && sh.q.pos[a0 + b - 1] > v) { sh.q.pos[a0 + b] = sh.q.pos[a0 + b - 1]; --b; }
+                            sh.q.pos[a0 + b] = v;
+                        }
+                        const uint32_t p0 = sh.q.pos[a0];
+                        atomicOr(&sh.q.headbits[p0 >> 6], 1ull << (p0 & 63u));
+                    }
+                }
+                __syncthreads();
+                if (tid < 64) {                                         // voxels in front of every 64-position word
+                    const uint32_t c = tid < (int)(VF_CAP / 64) ? (uint32_t)__popcll(sh.q.headbits[tid]) : 0u;
+                    const uint32_t incl = wave_scan_incl(c);
+                    if (tid < (int)(VF_CAP / 64)) sh.q.headpre[tid] = incl - c;
+                }
+                static_assert(VF_CAP / 64 <= 64, "one wave scans the head words");
+            } else {
+                skip_early = true;                                      // the count is out already; sort stably below
+            }
+            __syncthreads();
+            VX_STAMP(1);
+        }
+        if (R == 0 || grouped) {
+            // a reserved slot that was not needed (publishes zero voxels below), or grouped above
         } else if (R <= (uint32_t)VF_CAP && sortbits <= 32) {
             // ---------------- LDS path: keys once, stable LSD passes over (key, position) ----------------
             in_lds = true;
@@ -541,7 +668,7 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
             // are inserted into an exact hash set (open addressing, 2 * VF_CAP slots in the still unused key
             // buffers) while they are computed, so nobody waits for this batch's sort (the batch's own prefix is
             // only fetched at the end).
-            const bool early = sortbits <= 31;             // 0xFFFFFFFF marks an empty slot
+            const bool early = sortbits <= 31 && !skip_early;   // 0xFFFFFFFF marks an empty slot
             uint32_t* hset = &sh.key[0][0];
             constexpr uint32_t HSLOTS = 2 * VF_CAP;
             uint32_t fresh = 0;                            // keys this thread was the first to insert
@@ -565,7 +692,7 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
                 for (uint32_t j = tid; j < HSLOTS; j += VF_THREADS) hset[j] = 0xFFFFFFFFu;
                 __syncthreads();
             }
-            announced = early;
+            announced = early || skip_early;
             if (!selecting) {
                 uint32_t kreg[VP_ROUNDS];
 #pragma unroll
@@ -822,10 +949,11 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
         const int64_t vbase = sh.vbase;
         VX_STAMP(4);
         if (tid == 0) {
-            // *out_m starts at 0: the last batch adds the total, a batch whose wait ran out of its budget adds
-            // -2^62 - the sum is negative iff some batch failed, in whatever order the two happen
+            // *out_m starts at 0: the last batch adds the total (< 2^62), a batch whose wait ran out of its budget
+            // sets the sign bit (idempotent: every batch behind a poisoned one fails too) - the word reads negative
+            // iff some batch failed, in whatever order the two happen
             unsigned long long* om = reinterpret_cast<unsigned long long*>(out_m);
-            if (sh.lb_failed) atomicAdd(om, (unsigned long long)(-(1ll << 62)));
+            if (sh.lb_failed) atomicOr(om, 1ull << 63);
             if (first_of_chunk && out_chunk_offsets) out_chunk_offsets[c] = vbase;
             if (t == nbatches - 1 && !sh.lb_failed) {
                 atomicAdd(om, (unsigned long long)(vbase + nvox));
@@ -833,7 +961,28 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
             }
         }
         // ---- reduce: one thread per voxel, rows added in file order (AccumulatedPoint::AddPoint)
-        if (in_lds) {
+        if (grouped) {
+            // the thread whose row arrived first on a slot reduces that voxel (slot and key are still in its registers)
+#pragma unroll
+            for (int r = 0; r < VP_ROUNDS; ++r) {
+                if (ghs[r] != 0xFFFFFFFFu && (ghs[r] >> 16) == 0u) {
+                    const uint32_t slot = ghs[r] & 0xFFFFu;
+                    const uint32_t a0 = sh.q.sstart[slot];
+                    const uint32_t cn = (sh.q.hcnt[slot >> 2] >> (8 * (slot & 3u))) & 255u;
+                    const uint32_t p0 = sh.q.pos[a0];
+                    double ax = 0.0, ay = 0.0, az = 0.0;
+                    for (uint32_t a = 0; a < cn; ++a) {
+                        const Row q = bufA[s + sh.q.pos[a0 + a]];
+                        ax += q.x; ay += q.y; az += q.z;
+                    }
+                    const uint32_t v = sh.q.headpre[p0 >> 6] +
+                                       (uint32_t)__popcll(sh.q.headbits[p0 >> 6] & ((1ull << (p0 & 63u)) - 1ull));
+                    const uint64_t sk = gkey[r];
+                    const uint64_t key = ((d0 + (sk >> g.rem)) << g.rem) | (sk & remmask);
+                    vf_emit(g, key, ax, ay, az, cn, vbase + v, out_idx, out_mean, out_count);
+                }
+            }
+        } else if (in_lds) {
             for (uint32_t v = tid; v < nvox; v += VF_THREADS) {
                 const uint32_t a0 = vst[v], a1 = v + 1 < nvox ? vst[v + 1] : R;
                 double ax = 0.0, ay = 0.0, az = 0.0;

@@ -168,32 +168,195 @@ def _hull_triangles(points):
 
 
 # ---- many clusters at once -------------------------------------------------------------
-# The boxes of different clusters are independent, and qhull + the direction search hold the
-# GIL, so threads do not help.  PCH_OBB_WORKERS > 1 spreads the clusters over worker PROCESSES:
-# plain `python -m pointcloudhookup_amd.obb --worker` children that import only this module
-# (never the host application's main script, never a GPU context) and answer pickled requests
-# on their pipes.  Every cluster is still computed by bounding_box_oriented on the same points,
-# so the results are identical to the serial loop; results come back in input order.
-_WORKERS = []
+# The boxes of different clusters are independent and cost ~0.15 us of qhull per point (7 ms for a 43 000-point
+# tower), so they are spread over a pool of worker PROCESSES: plain `python -m pointcloudhookup_amd.obb --worker`
+# children that import only this module (never the host application's main script, never the HIP runtime: the
+# candidate search they run comes from the host-only libpch_obbhost.so).  Hand-off (round 4): the points of all
+# clusters lie in ONE shared-memory buffer (a memfd the parent maps, registers with the HIP runtime so that the
+# device copies straight into it, and the workers map through /proc/<parent>/fd/<n>); a task is a few dozen bytes
+# (path, offset, rows), an answer is the finished box (19 doubles) - nothing large is pickled or piped.  One
+# dispatcher thread in the parent feeds idle workers from a global task queue (largest clusters first) and collects
+# the answers; several jobs may be in flight, so the boxes of tile k are computed while the device clusters tile k+1.
+# Every cluster is still computed by the statements of bounding_box_oriented on the same points (hull ->
+# candidates -> native pricing -> python arithmetic for the winner), so the results are the serial loop's.
+_TIE = 1e-9          # candidates whose volume is within this (relative) of the smallest are decided by the python arithmetic
+_HOSTLIB = None
+
+
+def _hostlib():
+    """libpch_obbhost.so (include/pch_obbhost.h), or None when it is not built (the python loop then prices)."""
+    global _HOSTLIB
+    if _HOSTLIB is None:
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpch_obbhost.so")
+        try:
+            lib = C.CDLL(path)
+            lib.pch_obbhost_search_f64.restype = C.c_int
+            lib.pch_obbhost_search_f64.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+            _HOSTLIB = lib
+        except OSError:
+            _HOSTLIB = False
+    return _HOSTLIB or None
+
+
+def _winners(verts, angles):
+    """Indices of the candidate directions that can win (native pricing of all of them, then everything within
+    _TIE of the smallest volume), or None = evaluate all of them in python."""
+    lib = _hostlib()
+    if lib is None or len(angles) == 0:
+        return None
+    import ctypes as C
+    v = np.ascontiguousarray(verts, dtype=np.float64)
+    a = np.ascontiguousarray(angles, dtype=np.float64).reshape(-1, 2)
+    vol = np.empty(len(a), dtype=np.float64)
+    best = C.c_int32(-1)
+    rc = lib.pch_obbhost_search_f64(v.ctypes.data, len(v), a.ctypes.data, len(a), C.addressof(best), vol.ctypes.data)
+    if rc != 0 or best.value < 0:
+        return None                            # no rectangle anywhere: the python loop reports it its way
+    return np.flatnonzero(vol <= vol[best.value] * (1.0 + _TIE))
 
 
 def _boxed(args):
-    points, extent_order = args
+    points, what = args
     try:
-        if extent_order == "__hull__":        # first half only: the native search runs in the caller
+        if what == "__hull__":                 # first half only: the search runs in the caller
             return hull_candidates(points), None
-        if extent_order == "__hulltri__":     # fast mode: hull vertices + qhull's triangles for pch_obb_min_boxes_f64
+        if what == "__hulltri__":              # fast mode: hull vertices + qhull's triangles for pch_obb_min_boxes_f64
             return _hull_triangles(points), None
-        return bounding_box_oriented(points, extent_order), None
-    except Exception as e:                    # reported per cluster, like the serial loop does
+        if what.startswith("native:"):         # the whole exact box: hull, candidates, native pricing, python winner
+            verts, angles = hull_candidates(points)
+            to_origin, extents = bounds_from_candidates(verts, angles, what[7:], _winners(verts, angles))
+            return (extents, np.linalg.inv(to_origin)), None
+        return bounding_box_oriented(points, what), None
+    except Exception as e:                     # reported per cluster, like the serial loop does
         return None, e
 
 
-# candidates whose volume is within this (relative) of the smallest are decided by the python arithmetic
-_TIE = 1e-9
+def usable_cpus():
+    """cores this process may really use: affinity mask, cut by a cgroup CPU quota where one is readable"""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = min(n, max(1, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
 
 
-class _Worker:
+POOL_CAP = 64         # worker processes at most (a 100 M-point tile has ~230 clusters; beyond ~4 per worker the tail idles)
+
+
+def default_workers():
+    """PCH_OBB_WORKERS, else one worker per usable core up to POOL_CAP"""
+    import os
+    env = os.environ.get("PCH_OBB_WORKERS")
+    return max(1, int(env)) if env else min(POOL_CAP, usable_cpus())
+
+
+def _send(fh, obj):
+    import pickle
+    import struct
+    data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+    fh.write(struct.pack("<I", len(data)) + data)
+    fh.flush()
+
+
+class Buffer:
+    """A shared-memory buffer the workers can map: a memfd (freed by the kernel when the last mapping goes - nothing
+    can leak into /dev/shm), named /proc/<pid>/fd/<n> for the workers.  ``pin()`` registers it with the HIP runtime
+    so that a device-to-host copy goes straight into it."""
+
+    _count = 0
+
+    def __init__(self, nbytes):
+        import mmap
+        import os
+        self.nbytes = int(max(nbytes, 1 << 16))
+        try:
+            self.fd = os.memfd_create("pch_obb")
+            self.path = f"/proc/{os.getpid()}/fd/{self.fd}"
+        except (AttributeError, OSError):                        # no memfd: a named file under /dev/shm
+            import tempfile
+            self.fd, self.path = tempfile.mkstemp(prefix=f"pch_obb_{os.getpid()}_", dir="/dev/shm")
+            self._unlink = self.path
+        os.ftruncate(self.fd, self.nbytes)
+        self.map = mmap.mmap(self.fd, self.nbytes)
+        self.array = np.frombuffer(self.map, dtype=np.uint8)
+        self.pinned = False
+        self.busy = False
+        Buffer._count += 1
+        self.where = (self.path, self.nbytes, f"{os.getpid()}.{Buffer._count}")     # what a task carries
+
+    def pin(self):
+        if not self.pinned:
+            try:
+                import torch
+                rc = torch.cuda.cudart().cudaHostRegister(self.array.ctypes.data, self.nbytes, 0)
+                self.pinned = (rc is None) or (int(rc) == 0)
+            except Exception:
+                self.pinned = False
+        return self.pinned
+
+    def tensor(self, dtype, count):
+        import torch
+        return torch.frombuffer(self.map, dtype=dtype, count=int(count))
+
+    def close(self):
+        import os
+        try:
+            if self.pinned:
+                import torch
+                torch.cuda.cudart().cudaHostUnregister(self.array.ctypes.data)
+        except Exception:
+            pass
+        self.array = None
+        try:
+            self.map.close()
+        except (BufferError, ValueError):
+            pass
+        try:
+            os.close(self.fd)
+        except OSError:
+            pass
+        if getattr(self, "_unlink", None):
+            try:
+                os.unlink(self._unlink)
+            except OSError:
+                pass
+
+
+class Job:
+    """One batch of tasks in the pool.  ``wait()`` returns the results in task order: (value, exception | None)."""
+
+    def __init__(self, ntasks):
+        import threading
+        self.results = [None] * ntasks
+        self.left = ntasks
+        self.done = threading.Event()
+        self.worker_s = 0.0                    # seconds the workers reported for this job's tasks (sum)
+        self.t_submit = self.t_done = 0.0
+        if ntasks == 0:
+            self.done.set()
+
+    def wait(self, timeout=None):
+        if not self.done.wait(timeout):
+            raise TimeoutError("box workers did not answer in time")
+        return self.results
+
+
+class _Proc:
     def __init__(self):
         import os
         import subprocess
@@ -201,40 +364,297 @@ class _Worker:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ)
         env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+            env[var] = "1"                     # one core per worker: the pool is the parallelism
         self.proc = subprocess.Popen([sys.executable, "-m", "pointcloudhookup_amd.obb", "--worker"],
                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+        self.fd = self.proc.stdout.fileno()
+        os.set_blocking(self.fd, False)
+        self.buf = bytearray()
+        self.task = None                       # (job, index, request) in flight
+        self.alive = True
 
-    def ask(self, args):
+
+class Pool:
+    """Worker processes + one dispatcher thread.  submit(requests) -> Job."""
+
+    def __init__(self):
+        import collections
+        import os
+        import threading
+        self.procs = []
+        self.queue = collections.deque()       # (job, index, request), in submission order
+        self.lock = threading.Lock()
+        self.wake_r, self.wake_w = os.pipe()
+        os.set_blocking(self.wake_r, False)
+        os.set_blocking(self.wake_w, False)
+        self.stopping = False
+        self.thread = None
+        self.buffers = []
+
+    # ---- workers
+    def grow(self, n):
+        with self.lock:
+            while sum(p.alive for p in self.procs) < n:        # workers that died are replaced
+                self.procs.append(_Proc())
+            if self.thread is None:
+                import threading
+                self.thread = threading.Thread(target=self._run, name="pch-obb-dispatch", daemon=True)
+                self.thread.start()
+        self._wake()
+
+    def size(self):
+        return sum(p.alive for p in self.procs)
+
+    def _wake(self):
+        import os
+        try:
+            os.write(self.wake_w, b"x")
+        except (BlockingIOError, OSError):
+            pass
+
+    # ---- shared buffers (a small ring: one per job in flight)
+    def buffer(self, nbytes, pin=False):
+        with self.lock:
+            best = None
+            for b in self.buffers:
+                if not b.busy and b.nbytes >= nbytes and (best is None or b.nbytes < best.nbytes):
+                    best = b
+            if best is None:
+                for b in [b for b in self.buffers if not b.busy]:       # too small: replaced, not accumulated
+                    self.buffers.remove(b)
+                    b.close()
+                best = Buffer(int(nbytes * 1.25) + (1 << 20))
+                self.buffers.append(best)
+            best.busy = True
+        if pin:
+            best.pin()
+        return best
+
+    def release(self, buf):
+        with self.lock:
+            buf.busy = False
+
+    # ---- jobs
+    def submit(self, requests):
+        import time
+        job = Job(len(requests))
+        job.t_submit = time.perf_counter()
+        if requests:
+            with self.lock:
+                for i, r in enumerate(requests):
+                    self.queue.append((job, i, r))
+            self._wake()
+        return job
+
+    def _finish(self, job, index, value):
+        import time
+        job.results[index] = value
+        job.left -= 1
+        if job.left == 0:
+            job.t_done = time.perf_counter()
+            job.done.set()
+
+    def _run(self):
+        import os
         import pickle
-        pickle.dump(args, self.proc.stdin, protocol=pickle.HIGHEST_PROTOCOL)
-        self.proc.stdin.flush()
-        return pickle.load(self.proc.stdout)
+        import selectors
+        import struct
+        sel = selectors.DefaultSelector()
+        sel.register(self.wake_r, selectors.EVENT_READ, None)
+        known = set()
+        while not self.stopping:
+            with self.lock:
+                procs = list(self.procs)
+            for p in procs:
+                if p.alive and id(p) not in known:
+                    known.add(id(p))
+                    sel.register(p.fd, selectors.EVENT_READ, p)
+            # hand tasks to idle workers
+            for p in procs:
+                if not p.alive or p.task is not None:
+                    continue
+                with self.lock:
+                    item = self.queue.popleft() if self.queue else None
+                if item is None:
+                    break
+                try:
+                    _send(p.proc.stdin, item[2])
+                    p.task = item
+                except (OSError, ValueError):
+                    self._dead(sel, p, item)
+            if not any(p.alive for p in procs):                  # nobody left: compute here
+                while True:
+                    with self.lock:
+                        item = self.queue.popleft() if self.queue else None
+                    if item is None:
+                        break
+                    self._finish(item[0], item[1], _answer(item[2])[0])
+            for key, _ in sel.select(timeout=0.5):
+                if key.data is None:
+                    try:
+                        os.read(self.wake_r, 4096)
+                    except (BlockingIOError, OSError):
+                        pass
+                    continue
+                p = key.data
+                try:
+                    chunk = os.read(p.fd, 1 << 16)
+                except BlockingIOError:
+                    continue
+                except OSError:
+                    chunk = b""
+                if not chunk:
+                    self._dead(sel, p, p.task)
+                    continue
+                p.buf += chunk
+                while len(p.buf) >= 4:
+                    (ln,) = struct.unpack_from("<I", p.buf, 0)
+                    if len(p.buf) < 4 + ln:
+                        break
+                    value, secs = pickle.loads(bytes(p.buf[4:4 + ln]))
+                    del p.buf[:4 + ln]
+                    job, index, _ = p.task
+                    p.task = None
+                    job.worker_s += secs
+                    self._finish(job, index, value)
+                    with self.lock:                              # next task at once, without another pass
+                        item = self.queue.popleft() if self.queue else None
+                    if item is not None:
+                        try:
+                            _send(p.proc.stdin, item[2])
+                            p.task = item
+                        except (OSError, ValueError):
+                            self._dead(sel, p, item)
+
+    def _dead(self, sel, p, item):
+        """a worker that went away: its task (if any) is computed in the dispatcher, the rest goes to the others"""
+        if p.alive:
+            p.alive = False
+            try:
+                sel.unregister(p.fd)
+            except (KeyError, ValueError):
+                pass
+        p.task = None
+        if item is not None:
+            self._finish(item[0], item[1], _answer(item[2])[0])
 
     def close(self):
+        self.stopping = True
+        self._wake()
+        for p in self.procs:
+            try:
+                p.proc.stdin.close()
+                p.proc.wait(timeout=2)
+            except Exception:
+                p.proc.kill()
+        for b in self.buffers:
+            b.close()
+        self.buffers = []
+
+
+_POOL = None
+
+
+def pool(workers=None):
+    """the process-wide pool, grown to ``workers`` (default_workers()) processes"""
+    global _POOL
+    if _POOL is None:
+        import atexit
+        _POOL = Pool()
+        atexit.register(_POOL.close)
+    n = default_workers() if workers is None else int(workers)
+    if n > _POOL.size():
+        _POOL.grow(n)
+    return _POOL
+
+
+def prestart(workers=None):
+    """Starts the worker processes without waiting for them (their ~1 s of imports then runs beside the
+    caller's own work).  The drop-in calls this before it touches the file."""
+    n = default_workers() if workers is None else int(workers)
+    if n > 1:
+        pool(n)
+
+
+_MAPS = {}            # worker side: buffer id -> uint8 array over its mapping
+
+
+def _mapped(path, nbytes, ident):
+    """the parent's buffer `ident` mapped read-only (cached; the parent keeps a small ring of buffers, and a path
+    /proc/<pid>/fd/<n> may name another buffer later - hence the id).  Old mappings are dropped, not closed: they
+    go when the last array over them goes."""
+    import mmap
+    import os
+    arr = _MAPS.get(ident)
+    if arr is None:
+        while len(_MAPS) >= 4:
+            _MAPS.pop(next(iter(_MAPS)))
+        fd = os.open(path, os.O_RDONLY)
         try:
-            self.proc.stdin.close()
-            self.proc.wait(timeout=5)
-        except Exception:
-            self.proc.kill()
+            arr = np.frombuffer(mmap.mmap(fd, nbytes, prot=mmap.PROT_READ), dtype=np.uint8)
+        finally:
+            os.close(fd)
+        _MAPS[ident] = arr
+    return arr
 
 
-def _workers(n):
-    import atexit
-    if not _WORKERS:
-        atexit.register(lambda: [w.close() for w in _WORKERS])
-    while len(_WORKERS) < n:
-        _WORKERS.append(_Worker())
-    return _WORKERS[:n]
+def _answer(req):
+    """one request -> ((value, exception | None), seconds).  Runs in a worker (or in the parent's dispatcher when
+    no worker is left).  Requests: ("shm", (path, nbytes, id), byte offset, rows, dtype, what) | ("inline", array,
+    what)."""
+    import time
+    t0 = time.perf_counter()
+    try:
+        if req[0] == "shm":
+            _, where, off, rows, dtype, what = req
+            item = np.dtype(dtype).itemsize * 3
+            pts = _mapped(*where)[off:off + rows * item].view(dtype).reshape(rows, 3)
+        else:
+            _, pts, what = req
+        out = _boxed((pts, what))
+    except Exception as e:
+        out = (None, e)
+    return out, time.perf_counter() - t0
+
+
+def boxes_job(buf, offsets, dtype, extent_order="unsorted", workers=None, order=None):
+    """Submits the exact boxes of the clusters laid out in ``buf`` (a Buffer): cluster k = rows
+    [offsets[k], offsets[k+1]) of the [*,3] ``dtype`` array at the buffer's start.  Returns a Job whose results
+    are ((extents, transform), None) | (None, exception) per cluster, in cluster order."""
+    if extent_order not in _EXTENT_ORDERS:
+        raise ValueError(f"extent_order must be one of {_EXTENT_ORDERS}")
+    pl = pool(workers)
+    item = np.dtype(dtype).itemsize * 3
+    k = len(offsets) - 1
+    reqs = [("shm", buf.where, int(offsets[i]) * item, int(offsets[i + 1] - offsets[i]),
+             np.dtype(dtype).str, "native:" + extent_order) for i in range(k)]
+    # largest first: the tail of the job is then made of small clusters.  The Job keeps cluster order.
+    sizes = np.diff(np.asarray(offsets, dtype=np.int64))
+    perm = np.argsort(-sizes, kind="stable")
+    job = pl.submit([reqs[i] for i in perm])
+    job.perm = perm
+    return job
+
+
+def job_results(job, timeout=None):
+    """results of a boxes_job in cluster order"""
+    res = job.wait(timeout)
+    out = [None] * len(res)
+    for slot, i in enumerate(job.perm):
+        out[int(i)] = res[slot]
+    return out
 
 
 def boxes_of(clusters, extent_order="unsorted", workers=None, search=None):
     """Yields ((extents, transform), None) or (None, exception) for every (n_k,3) array in
-    ``clusters``, in order.  workers: None -> PCH_OBB_WORKERS; unset: up to 8 worker processes once there are
-    at least 16 clusters (a 100 M-point tile has hundreds, ~10 ms of qhull each), none for small jobs.
+    ``clusters``, in order.  workers: None -> PCH_OBB_WORKERS; unset: the pool (one worker per usable core, up to
+    POOL_CAP) once there are at least 16 clusters (a 100 M-point tile has hundreds, ~7 ms of qhull each), none for
+    small jobs.
     search: "native" (default, env PCH_OBB_SEARCH) - qhull and the candidate directions per cluster as below,
-    then ONE call of pch_obb_search_f64 prices every direction of every cluster and only the directions within
-    1e-9 of the smallest volume (usually one) go through this module's python arithmetic; "python" - the loop
-    over all ~80 directions in python.  The boxes are identical either way."""
+    then every direction of the cluster is priced natively (pch_obb_search_f64's code, in the worker) and only the
+    directions within 1e-9 of the smallest volume (usually one) go through this module's python arithmetic;
+    "python" - the loop over all ~80 directions in python.  The boxes are identical either way."""
     import os
     clusters = list(clusters)
     if extent_order not in _EXTENT_ORDERS:
@@ -244,77 +664,34 @@ def boxes_of(clusters, extent_order="unsorted", workers=None, search=None):
     if search not in ("native", "python"):
         raise ValueError("search must be 'native' or 'python'")
     if workers is None:
-        env = os.environ.get("PCH_OBB_WORKERS")
-        workers = int(env) if env else (min(8, os.cpu_count() or 1) if len(clusters) >= 16 else 1)
-    first = _per_cluster(clusters, "__hull__" if search == "native" else extent_order, workers)
-    if search == "python":
-        yield from first
-        return
-    ok = [i for i, (h, e) in enumerate(first) if e is None]
-    winners = {}
-    if ok:
-        from . import ops
-        vo = np.cumsum([0] + [len(first[i][0][0]) for i in ok])
-        ao = np.cumsum([0] + [len(first[i][0][1]) for i in ok])
-        best, vol = ops.obb_search(np.concatenate([first[i][0][0] for i in ok]), vo,
-                                   np.concatenate([first[i][0][1].reshape(-1, 2) for i in ok]), ao)
-        for j, i in enumerate(ok):
-            if best[j] >= 0:
-                v = vol[ao[j]:ao[j + 1]]
-                winners[i] = np.flatnonzero(v <= v[best[j]] * (1.0 + _TIE))
-            else:
-                winners[i] = None              # no rectangle anywhere: the python loop reports it its way
-    for i, (h, e) in enumerate(first):
-        if e is not None:
-            yield None, e
-            continue
-        try:
-            to_origin, extents = bounds_from_candidates(h[0], h[1], extent_order, winners[i])
-            yield (extents, np.linalg.inv(to_origin)), None
-        except Exception as e2:
-            yield None, e2
-
-
-def prestart(workers=None):
-    """Starts the worker processes without waiting for them (their ~1 s of imports then runs beside the
-    caller's own work).  The drop-in calls this before it touches the file."""
-    import os
-    if workers is None:
-        env = os.environ.get("PCH_OBB_WORKERS")
-        workers = int(env) if env else min(8, os.cpu_count() or 1)
-    if workers > 1:
-        _workers(int(workers))
+        workers = default_workers() if (len(clusters) >= 16 or os.environ.get("PCH_OBB_WORKERS")) else 1
+    what = ("native:" + extent_order) if search == "native" else extent_order
+    yield from _per_cluster(clusters, what, workers)
 
 
 def _per_cluster(clusters, what, workers):
-    """[_boxed((c, what)) for c in clusters], spread over worker processes when asked to."""
+    """[_boxed((c, what)) for c in clusters], spread over the worker pool when asked to: the arrays are packed into
+    one shared buffer, the tasks name their slices."""
     if workers <= 1 or len(clusters) < 2:
         return [_boxed((c, what)) for c in clusters]
-    import queue
-    import threading
-    tasks = queue.SimpleQueue()
-    for i, c in enumerate(clusters):
-        tasks.put((i, np.ascontiguousarray(c)))
-    results = [None] * len(clusters)
-
-    def serve(w):                              # one thread per worker process: request, answer, next
-        while True:
-            try:
-                i, c = tasks.get_nowait()
-            except queue.Empty:
-                return
-            try:
-                results[i] = w.ask((c, what))
-            except Exception as e:            # a dead worker: compute here instead
-                results[i] = _boxed((c, what)) if not isinstance(e, KeyboardInterrupt) else (None, e)
-
-    threads = [threading.Thread(target=serve, args=(w,), daemon=True)
-               for w in _workers(min(int(workers), len(clusters)))]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    return results
+    arrs = [np.ascontiguousarray(c) for c in clusters]
+    pl = pool(workers)
+    ok = all(a.ndim == 2 and a.shape[1] == 3 and a.dtype == arrs[0].dtype and a.dtype.kind == "f" for a in arrs)
+    if not ok:                                 # odd shapes / dtypes: the arrays travel inline
+        return pl.submit([("inline", a, what) for a in arrs]).wait()
+    item = arrs[0].dtype.itemsize * 3
+    offs = np.cumsum([0] + [len(a) for a in arrs])
+    buf = pl.buffer(int(offs[-1]) * item)
+    try:
+        flat = buf.array[:int(offs[-1]) * item].view(arrs[0].dtype).reshape(-1, 3)
+        for a, lo in zip(arrs, offs[:-1]):
+            flat[lo:lo + len(a)] = a
+        del flat
+        reqs = [("shm", buf.where, int(offs[i]) * item, len(arrs[i]), arrs[0].dtype.str, what)
+                for i in range(len(arrs))]
+        return pl.submit(reqs).wait()
+    finally:
+        pl.release(buf)
 
 
 # ---- fast mode --------------------------------------------------------------------------------
@@ -343,8 +720,8 @@ def boxes_fast(points, perm, offsets, nclusters, extent_order="unsorted", nthrea
     results = [None] * K
     hulls = []
     parts = [kept[bounds[k]:bounds[k + 1]] for k in range(K)]
-    if workers is None:                       # worker processes that are already running take the hulls (qhull holds the GIL)
-        workers = len(_WORKERS) if K >= 16 else 1
+    if workers is None:                       # worker processes that are already running take the hulls
+        workers = (_POOL.size() if _POOL is not None else 0) if K >= 16 else 1
     for k, (h, e) in enumerate(_per_cluster(parts, "__hulltri__", workers)):
         if e is not None:                     # QhullError: too few / degenerate points
             results[k] = (None, e)
@@ -366,14 +743,16 @@ def boxes_fast(points, perm, offsets, nclusters, extent_order="unsorted", nthrea
 
 if __name__ == "__main__":
     import pickle
+    import struct
     import sys
     if "--worker" in sys.argv:
         inp, out = sys.stdin.buffer, sys.stdout.buffer
         sys.stdout = sys.stderr                # stray prints must not corrupt the answer stream
+        _hostlib()
         while True:
-            try:
-                req = pickle.load(inp)
-            except EOFError:
+            head = inp.read(4)
+            if len(head) < 4:
                 break
-            pickle.dump(_boxed(req), out, protocol=pickle.HIGHEST_PROTOCOL)
-            out.flush()
+            (ln,) = struct.unpack("<I", head)
+            req = pickle.loads(inp.read(ln))
+            _send(out, _answer(req))

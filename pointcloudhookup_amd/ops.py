@@ -73,8 +73,8 @@ def get_profile():
 # ---------------------------------------------------------------------------- stage A
 def voxel_downsample(xyz, voxel_size, chunk_size=0):
     """Per-chunk voxel-grid downsample.  Returns (idx int32 [m,3], mean f64 [m,3],
-    count int32 [m], chunk_offsets int64 [nchunks+1]); rows grouped by chunk, sorted by
-    (ix,iy,iz) inside a chunk.  Synchronises (reads m)."""
+    count int32 [m], chunk_offsets int64 [nchunks+1]); rows grouped by chunk; the order inside a
+    chunk is deterministic but not sorted (include/pch_hip.h; Open3D's own is unspecified).  Synchronises (reads m)."""
     L = _lib.lib()
     xyz = _need_cuda(xyz, torch.float64, "xyz").reshape(-1, 3)
     n = xyz.shape[0]

@@ -37,30 +37,70 @@ import torch.distributed as dist
 # (a few KB each) instead of losing the run.
 _EXCHANGE_GROUP = None
 
+# PCH_TILES_FORCE_COLLECTIVES=1: a world of ONE rank still takes the multi-rank branch of every function below -
+# every all_gather / all_reduce / broadcast is really issued (on RCCL when the group is "nccl": init_from_env then
+# brings a one-rank nccl group up) instead of being short-circuited.  The only calls a single rank cannot make are the
+# point-to-point hops of the centroid chain.  A test / rehearsal switch: it makes the RCCL code paths executable on a
+# one-GPU box (tests/test_gpu_e2e.py), results are unchanged.
+_FORCE = os.environ.get("PCH_TILES_FORCE_COLLECTIVES", "0") == "1"
+
 
 def _pg(group):
     return group if group is not None else _EXCHANGE_GROUP
 
 
+COLLECTIVES = {}      # name -> calls issued by this module in this process (tests / bench: how many per step?)
+
+
+def _count(name):
+    COLLECTIVES[name] = COLLECTIVES.get(name, 0) + 1
+
+
+def _multi(group):
+    """do the exchanges of this module really run (more than one rank, or forced)?"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or _FORCE
+
+
 def exchange_backend():
     """'nccl' (= RCCL on ROCm), 'gloo' or 'none': what carries the exchanges of this module by default."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _multi(_EXCHANGE_GROUP):
         return "none"
     return dist.get_backend(_EXCHANGE_GROUP)
 
 
-def init_from_env(backend=None, timeout_s=None):
-    """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* when WORLD_SIZE > 1.
+def init_from_env(backend=None, timeout_s=None, single_device=False):
+    """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* when WORLD_SIZE > 1 (or when
+    PCH_TILES_FORCE_COLLECTIVES=1 asks for a one-rank group).
     backend: "nccl" / "gloo" (also env PCH_DIST_BACKEND) = that backend for everything.  None on a GPU node: the
-    default group is gloo and an RCCL group over all ranks is PROBED - created, one small all-reduce on the device,
-    the outcome agreed over gloo; if every rank succeeded the exchanges of this module use it (exchange_backend() ==
-    'nccl'), otherwise they stay on gloo and rank 0 says so.
+    default group is gloo and an RCCL group over all ranks is PROBED - created (outcome agreed over gloo BEFORE
+    anybody enters a device collective), then one small all-reduce on the device with a short wait of its own, the
+    outcome agreed over gloo again; if every rank succeeded the exchanges of this module use it
+    (exchange_backend() == 'nccl'), otherwise they stay on gloo and rank 0 says so.  A rank that fails asymmetrically
+    INSIDE the device all-reduce cannot be recovered from (the others sit in the collective until its timeout and the
+    watchdog then aborts the process): the probe only removes the failures that show before that point.
     ``timeout_s`` bounds every collective (a rank that died leaves the others waiting at most that long).
+    ``single_device``: all ranks use device 0 (a rehearsal on a one-GPU box; RCCL then refuses and gloo carries on).
     Returns (rank, world, local_rank)."""
     global _EXCHANGE_GROUP
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and _FORCE and not dist.is_initialized():
+        import socket
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
+        if backend is None:
+            backend = os.environ.get("PCH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=0, world_size=1)
+        _EXCHANGE_GROUP = None
+        return rank, world, local
     if world > 1 and not dist.is_initialized():
         kw = {}
         if timeout_s:
@@ -75,22 +115,35 @@ def init_from_env(backend=None, timeout_s=None):
             dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
             _EXCHANGE_GROUP = None
             return rank, world, local
-        devi = 0 if os.environ.get("PCH_BENCH_SINGLE_DEVICE") else local     # rehearsal: all ranks on device 0
+        devi = 0 if single_device else local                # rehearsal: all ranks on device 0
         torch.cuda.set_device(devi)
         dist.init_process_group(backend="gloo", rank=rank, world_size=world, **kw)
-        ok, why, g = 1, "", None
+
+        def agreed(ok):                                     # over gloo: every rank takes the same branch
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        ok, why, g = True, "", None
         try:
             g = dist.new_group(ranks=list(range(world)), backend="nccl", **kw)
-            t = torch.ones(1, device=torch.device("cuda", devi))
-            dist.all_reduce(t, group=g)
-            torch.cuda.synchronize()
-            if int(t.item()) != world:
-                ok, why = 0, f"all_reduce gave {t.item()} for {world} ranks"
-        except Exception as e:                              # e.g. two ranks on one device, IPC not available
-            ok, why = 0, f"{type(e).__name__}: {e}"
-        flag = torch.tensor([ok], dtype=torch.int64)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)         # over gloo: every rank takes the same branch
-        if int(flag.item()) == 1:
+        except Exception as e:
+            ok, why = False, f"new_group: {type(e).__name__}: {e}"
+        if agreed(ok):                                      # nobody enters the device collective unless all have a group
+            try:
+                import datetime
+                t = torch.ones(1, device=torch.device("cuda", devi))
+                work = dist.all_reduce(t, group=g, async_op=True)
+                work.wait(timeout=datetime.timedelta(seconds=min(60.0, float(timeout_s or 60.0))))
+                torch.cuda.synchronize()
+                if int(t.item()) != world:
+                    ok, why = False, f"all_reduce gave {t.item()} for {world} ranks"
+            except Exception as e:                          # e.g. two ranks on one device, IPC not available
+                ok, why = False, f"{type(e).__name__}: {e}"
+            ok = agreed(ok)
+        else:
+            ok = False
+        if ok:
             _EXCHANGE_GROUP = g
         else:
             _EXCHANGE_GROUP = None
@@ -120,7 +173,7 @@ def reconcile(nclusters, table, group=None):
              owner int64 [total] = rank that produced each row).
     """
     group = _pg(group)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _multi(group):
         owner = torch.zeros((int(nclusters),), dtype=torch.int64, device=table.device)
         return 0, int(nclusters), table[: int(nclusters)], owner
     world = dist.get_world_size(group)
@@ -146,6 +199,7 @@ def reconcile(nclusters, table, group=None):
         if m:
             block[1:1 + m] = table[:m].reshape(m, C)
         out = torch.empty((world * (cap + 1), C), dtype=table.dtype, device=dev)
+        _count("all_gather")
         try:
             dist.all_gather_into_tensor(out, block, group=group)
         except (RuntimeError, AttributeError, NotImplementedError):     # a backend without the flat form
@@ -240,15 +294,16 @@ def _mark(timings, label):
         timings["trace"].append((label, time.perf_counter()))
 
 
-# capacities of the two fixed-size exchanges of cluster_tiled (per rank): clusters, strip pairs, links.  A rank that
+# capacities of the fixed-size exchange of cluster_tiled (per rank): clusters, strip pairs per edge.  A rank that
 # holds more is seen by everybody in the block's header and ONE exactly sized exchange follows (same branch on all)
-TILED_KCAP, TILED_PCAP, TILED_LCAP = 2048, 4096, 1024
+TILED_KCAP, TILED_PCAP = 2048, 2048           # clusters per rank; strip cells per edge
 
 
 def _all_gather_block(block, group):
     """ONE collective: every rank's equally sized 1-D block -> [world, len] tensor on the block's device."""
     world = dist.get_world_size(group)
     out = torch.empty((world * block.numel(),), dtype=block.dtype, device=block.device)
+    _count("all_gather")
     try:
         dist.all_gather_into_tensor(out, block, group=group)
     except (RuntimeError, AttributeError, NotImplementedError):     # a backend without the flat form
@@ -258,26 +313,31 @@ def _all_gather_block(block, group):
     return out.reshape(world, block.numel())
 
 
-def _exchange(header, payloads, caps, comm_dev, group):
-    """All-gathers, in ONE collective, a block per rank = [len(payloads) counts | payload 0 padded to caps[0] | ...].
-    payloads: 1-D int64 tensors; header: their true lengths (ints, or 0-d device tensors that are never read on
-    this side).  If some rank's length exceeds its capacity, one more exchange sized by the largest lengths follows.
-    Returns (per-rank lists of numpy arrays, largest length of every payload over the ranks)."""
+def _exchange(header, payloads, caps, comm_dev, group, extra=()):
+    """All-gathers, in ONE collective, a block per rank = [len(payloads) counts | extra words | payload 0 padded to
+    caps[0] | ...].  payloads: 1-D int64 tensors; header: their true lengths (ints, or 0-d device tensors that are
+    never read on this side); extra: a few more int64 words per rank that ride along (ints).  If some rank's length
+    exceeds its capacity, one more exchange sized by the largest lengths follows.
+    Returns (per-rank lists of numpy arrays, largest length of every payload over the ranks, extra words [world, n])."""
+    nh = len(payloads) + len(extra)
+
     def pack(caps_now):
-        blk = torch.zeros((len(payloads) + sum(caps_now),), dtype=torch.int64, device=payloads[0].device)
-        at = len(payloads)
+        blk = torch.zeros((nh + sum(caps_now),), dtype=torch.int64, device=payloads[0].device)
+        at = nh
         for j, (p, c) in enumerate(zip(payloads, caps_now)):
             blk[j] = header[j] if torch.is_tensor(header[j]) else int(header[j])
             m = min(int(p.numel()), c)
             if m:
                 blk[at:at + m] = p[:m]
             at += c
+        for j, v in enumerate(extra):
+            blk[len(payloads) + j] = int(v)
         return blk
 
     def unpack(out, caps_now):
         res = []
         for r in range(out.shape[0]):
-            row, at, parts = out[r], len(payloads), []
+            row, at, parts = out[r], nh, []
             for j, c in enumerate(caps_now):
                 parts.append(row[at:at + min(int(row[j]), c)])
                 at += c
@@ -290,20 +350,89 @@ def _exchange(header, payloads, caps, comm_dev, group):
     if (need > np.asarray(caps)).any():                  # rare: a rank overflowed its block; everybody sees it
         caps = [int(max(c, n)) for c, n in zip(caps, need)]
         out = _all_gather_block(pack(caps).to(comm_dev), group).cpu().numpy()
-    return unpack(out, caps), [int(v) for v in need]
+    return unpack(out, caps), [int(v) for v in need], out[:, len(payloads):nh]
 
 
-def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fit=None, group=None, timings=None):
+def strip_representatives(points, rows, labels, core, x_from, x_to, eps):
+    """One (global row, local cluster) pair per LATTICE cell that holds a core point with x in [x_from, x_to).
+    The lattice is the same on every rank: cell = floor(double(coordinate) / side) per axis, side = eps/sqrt(3)
+    (1 - 2^-16), anchored at the origin of the (shared, centred) frame - so two tiles that both hold the points of
+    such a strip, with the same core flags, name the SAME rows: the smallest global core row of every cell.  Two
+    points of one cell are closer than eps, so the core points of a cell are one cluster in either tile.
+    points [n,3] float32, rows [n] int64 ascending, labels [n] int64, core [n] bool (same device).
+    Returns int64 [m,2] sorted by row."""
+    x = points[:, 0]
+    pick = core & (labels >= 0) & (x >= float(x_from)) & (x < float(x_to))
+    idx = torch.nonzero(pick).squeeze(1)
+    if idx.numel() == 0:
+        return torch.zeros((0, 2), dtype=torch.int64, device=points.device)
+    side = float(eps) / 3 ** 0.5 * (1.0 - 2.0 ** -16)
+    c = torch.floor(points.index_select(0, idx).to(torch.float64) / side).to(torch.int64) + (1 << 20)
+    if int(c.min()) < 0 or int(c.max()) >= (1 << 21):
+        raise ValueError("strip_representatives: coordinates beyond 2^20 lattice cells from the origin")
+    key = (c[:, 0] << 42) | (c[:, 1] << 21) | c[:, 2]
+    r = rows.index_select(0, idx)
+    _, inv = torch.unique(key, return_inverse=True)
+    ncell = int(inv.max()) + 1
+    rep = torch.full((ncell,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=points.device)
+    rep.scatter_reduce_(0, inv, r, reduce="amin")
+    first = r == rep.index_select(0, inv)               # the row that represents its cell (rows are distinct)
+    out = torch.stack([r[first], labels.index_select(0, idx)[first]], dim=1)
+    return out[torch.argsort(out[:, 0])]
+
+
+def union_links(total, links, minrow):
+    """Components of the graph (clusters 0..total-1, undirected links [m,2]) numbered by the smallest entry of
+    ``minrow`` (int64 [total]) inside each - sklearn's numbering of the whole cloud.  A union-find over the (few)
+    clusters that appear in a link; everything over the (many) clusters is vectorised, and the final ranking is a
+    stable sort of what is a concatenation of ascending runs (every rank numbers its clusters by first core row).
+    Returns (gid int64 [total], number of components)."""
+    total = int(total)
+    mr = np.asarray(minrow, dtype=np.int64)
+    root = np.arange(total, dtype=np.int64)
+    comp_min = mr
+    lk = np.asarray(links, dtype=np.int64).reshape(-1, 2)
+    if len(lk):
+        nodes, inv = np.unique(lk.reshape(-1), return_inverse=True)
+        parent = list(range(len(nodes)))
+
+        def find(a):
+            while parent[a] != a:
+                parent[a] = parent[parent[a]]
+                a = parent[a]
+            return a
+
+        for a, b in inv.reshape(-1, 2).tolist():
+            ra, rb = find(a), find(b)
+            if ra != rb:
+                parent[max(ra, rb)] = min(ra, rb)            # nodes ascend: the root is the smallest cluster index
+        loc = np.fromiter((find(i) for i in range(len(nodes))), dtype=np.int64, count=len(nodes))
+        root[nodes] = nodes[loc]
+        comp_min = mr.copy()
+        np.minimum.at(comp_min, nodes[loc], mr[nodes])
+    is_root = root == np.arange(total, dtype=np.int64)
+    roots = np.flatnonzero(is_root)
+    order = roots[np.argsort(comp_min[roots], kind="stable")]
+    gid_of_root = np.empty(total, dtype=np.int64)
+    gid_of_root[order] = np.arange(len(order), dtype=np.int64)
+    return gid_of_root[root], int(len(order))
+
+
+def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fit=None, group=None, timings=None,
+                  extra=()):
     """Global DBSCAN of a cloud that is spread over the ranks as x-tiles with a halo of at least 2*eps.
 
     points : [n,3] float32 points of THIS rank's tile, halo included (device tensor for the HIP fit)
     rows   : [n] int64 global row of every point (its index in the whole cloud; defines the cluster numbering),
              ASCENDING (the tile keeps the cloud's order)
     own    : [n] bool, True for the points this rank reports (x inside its own tile)
-    x_lo, x_hi : this rank's own x-range [x_lo, x_hi)
+    x_lo, x_hi : this rank's own x-range [x_lo, x_hi); neighbouring ranks must pass the SAME number for the edge
+             they share (the strips on either side of it are cut with it)
     halo   : width of the overlap on either side (default and minimum 2*eps); every rank must use the same
     timings: optional dict; "fit_ms" / "reconcile_ms" are ADDED to it (wall clock, the device drained in between)
-    Returns (labels int32 [n] for ALL local points (valid where ``own``), number of global clusters).
+    extra  : a few ints that ride along in the exchange; their per-rank values come back as the third result
+    Returns (labels int32 [n] for ALL local points (valid where ``own``), number of global clusters,
+             extra words of every rank: int64 [world, len(extra)]).
 
     Result for the owned points = one DBSCAN(eps, min_samples) over the whole cloud, ids = rank of the
     cluster's smallest core row (sklearn's numbering).  Why it is exact: a point's core flag is exact when
@@ -313,11 +442,12 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
     point (same global row, seen by two tiles) belong together.  Border points are re-decided after the
     renumbering on the device (their core neighbours all have exact flags).
 
-    The exchange: TWO collectives per call, each ONE all_gather of a fixed-capacity block per rank
-    whose header carries the true counts - (1) the smallest global core row of every local cluster + the
-    (global row, local cluster) pairs of the strip at the tile's upper edge, one pair per grid cell
-    (pch_dbscan_strip_pairs_i32); (2) the piece-to-piece links the right-hand tile found by looking those rows up in
-    its own labels.  The same union (scipy connected_components) then runs on every rank."""
+    The exchange: ONE collective per call - one all_gather of a fixed-capacity block per rank whose
+    header carries the true counts: the smallest global core row of every local cluster, and for BOTH edges of the
+    tile the (global row, local cluster) pairs of the strip [e - eps, e + eps) around the edge, one pair per cell of a
+    lattice every rank shares (strip_representatives: both neighbours hold the strip's points with exact core
+    flags, so both name the same rows).  Every rank then joins rank r's upper strip with rank r+1's lower strip on
+    the global row - the links between pieces - and runs the same union (union_links); no second exchange."""
     group = _pg(group)
     import time
     t_start = time.perf_counter()
@@ -326,7 +456,7 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
     k = int(k)
     t_fit = time.perf_counter()                            # fit() has read the cluster count: the device is drained
     _mark(timings, "fit")
-    single = not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1
+    single = not _multi(group)
     # bookkeeping stays where the points are (device tensors with the HIP fit): only the per-cluster table and
     # the pairs of the strip cells ever leave the device
     pts_t = torch.as_tensor(points)
@@ -345,7 +475,7 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
             minrow.scatter_reduce_(0, lab_d[cm], rows_d[cm], reduce="amin")
         minrow = minrow[:k]
 
-    def done(labels_out, total):
+    def done(labels_out, total, words):
         _mark(timings, "relabel_enqueued")
         if timings is not None and "trace" not in timings:
             if torch.as_tensor(labels_out).is_cuda:
@@ -353,13 +483,13 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
             t_end = time.perf_counter()
             timings["fit_ms"] = timings.get("fit_ms", 0.0) + 1e3 * (t_fit - t_start)
             timings["reconcile_ms"] = timings.get("reconcile_ms", 0.0) + 1e3 * (t_end - t_fit)
-        return labels_out, total
+        return labels_out, total, words
 
     if single:
         order = torch.argsort(minrow)
         cmap = torch.empty(k, dtype=torch.int64, device=wdev)
         cmap[order] = torch.arange(k, device=wdev)
-        return done(fit.relabel(cmap.to(torch.int32)), k)
+        return done(fit.relabel(cmap.to(torch.int32)), k, np.asarray([list(extra)], dtype=np.int64))
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     comm_dev = torch.device("cpu")
     if dist.get_backend(group) == "nccl":                 # RCCL moves device buffers (a few KB..MB over xGMI)
@@ -367,66 +497,39 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
     halo = 2.0 * float(eps) if halo is None else float(halo)
     if halo < 2.0 * float(eps):
         raise ValueError("halo must be at least 2*eps")
-    if float(x_hi) - float(x_lo) < halo:
+    if world > 1 and float(x_hi) - float(x_lo) < halo:
         raise ValueError("a tile must be at least one halo wide (only neighbouring tiles are matched)")
     # Which pieces belong together?  Every true core-core edge that crosses the tile edge e has an endpoint within
-    # eps of e, and such a point has its exact core flag in BOTH tiles.  So it is enough that the left tile of every
-    # edge publishes (global row, local cluster) for its core points with x in [e - eps, e + eps) - one per grid
-    # cell, since the core points of a cell are one cluster in either tile; the right tile looks those rows up in
-    # its own labels (on the device) and reports the distinct (left piece, right piece) links.
-    e_hi = float(x_hi)
-    pcap = TILED_PCAP
-    while True:
-        if rank == world - 1:                              # no tile to the right
-            pairs, npairs2 = torch.zeros((0,), dtype=torch.int64, device=wdev), 0
-        elif hasattr(fit, "strip_pairs"):
-            loc, cnt = fit.strip_pairs(e_hi - float(eps), e_hi + float(eps), pcap)
-            npairs2 = 2 * cnt.reshape(-1)[0].to(torch.int64)     # stays on the device: it travels in the header
-            n_here = int(rows_d.numel())
-            grow = (rows_d[loc[:, 0].long().clamp_(0, max(n_here - 1, 0))] if n_here
-                    else torch.zeros(pcap, dtype=torch.int64, device=wdev))
-            pairs = torch.stack([grow, loc[:, 1].long()], dim=1).reshape(-1)
-        else:
-            x_d = pts_t[:, 0]
-            strip = cm & (x_d >= e_hi - float(eps)) & (x_d < e_hi + float(eps))
-            pairs = torch.stack([rows_d[strip], lab_d[strip]], dim=1).reshape(-1)   # (global row, LOCAL cluster id)
-            npairs2 = int(pairs.numel())
-        _mark(timings, "pairs_built")
-        got, need = _exchange([k, npairs2], [minrow, pairs], [TILED_KCAP, 2 * pcap], comm_dev, group)
-        _mark(timings, "exchange1")
-        if not hasattr(fit, "strip_pairs") or need[1] <= 2 * pcap:
-            break
-        pcap = need[1] // 2                                # some strip has more cells than the pair buffer: once more
+    # eps of e, and such a point has its exact core flag in BOTH tiles.  So both tiles publish (global row, local
+    # cluster) for the core points with x in [e - eps, e + eps) - one per lattice cell, the same rows on either side.
+    none = torch.zeros((0, 2), dtype=torch.int64, device=wdev)
+    lower = none if rank == 0 else strip_representatives(pts_t, rows_d, lab_d, core_d, float(x_lo) - float(eps),
+                                                          float(x_lo) + float(eps), eps)
+    upper = none if rank == world - 1 else strip_representatives(pts_t, rows_d, lab_d, core_d,
+                                                                  float(x_hi) - float(eps), float(x_hi) + float(eps), eps)
+    _mark(timings, "pairs_built")
+    got, _, words = _exchange([k, 2 * int(lower.shape[0]), 2 * int(upper.shape[0])],
+                              [minrow, lower.reshape(-1), upper.reshape(-1)],
+                              [TILED_KCAP, 2 * TILED_PCAP, 2 * TILED_PCAP], comm_dev, group, extra=extra)
+    _mark(timings, "exchange1")
     counts = [int(g[0].shape[0]) for g in got]
     offs = np.concatenate([[0], np.cumsum(counts)])
     total = int(offs[-1])
-    links = torch.zeros((0, 2), dtype=torch.int64, device=wdev)
-    if rank > 0 and got[rank - 1][1].shape[0] and rows_d.numel():
-        theirs = torch.from_numpy(np.ascontiguousarray(got[rank - 1][1]).reshape(-1, 2)).to(wdev)
-        at = torch.searchsorted(rows_d, theirs[:, 0].contiguous()).clamp(max=rows_d.numel() - 1)      # rows ascend
-        hit = (rows_d[at] == theirs[:, 0]) & cm[at]
-        if hit.any():
-            links = torch.unique(torch.stack([theirs[hit, 1] + int(offs[rank - 1]), lab_d[at[hit]] + int(offs[rank])],
-                                             dim=1), dim=0)
-    _mark(timings, "links_built")
-    got2, _ = _exchange([2 * int(links.shape[0])], [links.reshape(-1)], [2 * TILED_LCAP], comm_dev, group)
-    _mark(timings, "exchange2")
     if total == 0:
-        return done(fit.relabel(torch.zeros(0, dtype=torch.int32)), 0)
-    # union over all local clusters (uid = rank offset + local id): components of the link graph, numbered by the
-    # smallest global core row of their pieces (sklearn's numbering of the whole cloud)
-    from scipy.sparse import coo_matrix
-    from scipy.sparse.csgraph import connected_components
-    lk = np.concatenate([g[0] for g in got2]).reshape(-1, 2)
-    graph = coo_matrix((np.ones(len(lk), np.int8), (lk[:, 0], lk[:, 1])), shape=(total, total))
-    ncomp, comp = connected_components(graph, directed=False)
-    mr = np.concatenate([g[0] for g in got])
-    comp_min = np.full(ncomp, np.iinfo(np.int64).max)
-    np.minimum.at(comp_min, comp, mr)
-    gid_of_comp = np.empty(ncomp, np.int64)
-    gid_of_comp[np.argsort(comp_min, kind="stable")] = np.arange(ncomp)
-    cmap = gid_of_comp[comp[offs[rank]:offs[rank] + k]]
-    return done(fit.relabel(torch.as_tensor(cmap, dtype=torch.int32)), int(ncomp))
+        return done(fit.relabel(torch.zeros(0, dtype=torch.int32)), 0, words)
+    # links: rank r's upper strip joined with rank r+1's lower strip on the global row (both sorted by row)
+    links = []
+    for r in range(world - 1):
+        up, lo = got[r][2].reshape(-1, 2), got[r + 1][1].reshape(-1, 2)
+        if len(up) and len(lo):
+            _, iu, il = np.intersect1d(up[:, 0], lo[:, 0], assume_unique=True, return_indices=True)
+            if len(iu):
+                links.append(np.stack([up[iu, 1] + offs[r], lo[il, 1] + offs[r + 1]], axis=1))
+    links = np.unique(np.concatenate(links), axis=0) if links else np.zeros((0, 2), np.int64)
+    _mark(timings, "links_built")
+    gid, ncomp = union_links(total, links, np.concatenate([g[0] for g in got]))
+    cmap = gid[offs[rank]:offs[rank] + k]
+    return done(fit.relabel(torch.as_tensor(cmap, dtype=torch.int32)), int(ncomp), words)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -451,22 +554,28 @@ class HipSelect:
         return ops.select_min_above(values, key)
 
 
-def shared_percentile(values, q_percent, sub=None, select=None, group=None):
+def shared_percentile(values, q_percent, sub=None, select=None, group=None, ride=None, first_hist=None):
     """np.percentile(concatenation of every rank's values - sub, q) in numpy >= 2 float32 semantics, bit for bit
     what pch_percentile_f32 gives for the concatenation: three all-reduced 4096-bin histogram passes locate the
     order statistic floor((N-1) q), one all-reduced minimum gives the next one, the lerp is numpy's.
     values: this rank's 1-D float32 values (device tensor for the HIP passes); sub: float32 subtracted from the
     two order statistics before the lerp (the centroid's z: x -> fl(x - sub) is monotone, so the select runs on
-    the raw values).  Returns np.float32."""
+    the raw values) - or a callable that receives the summed ``ride`` words and returns it.
+    ride: int64 words of this rank that are SUMMED over the ranks in the first exchange, beside the histogram - how
+    tiled_step broadcasts the centroid (only the last rank contributes non-zero bits) without a collective of its
+    own; first_hist: pass 0 of this rank, (hist, nan count), if the caller has already computed it.
+    Returns np.float32."""
     group = _pg(group)
     select = select or HipSelect()
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = _multi(group)
+    ride = np.zeros(0, dtype=np.int64) if ride is None else np.asarray(ride, dtype=np.int64).reshape(-1)
 
     def allsum(a):
         t = torch.as_tensor(np.asarray(a, dtype=np.int64))
         if multi:
             if dist.get_backend(group) == "nccl":
                 t = t.to(torch.as_tensor(values).device)
+            _count("all_reduce")
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         return t.cpu().numpy()
 
@@ -475,6 +584,7 @@ def shared_percentile(values, q_percent, sub=None, select=None, group=None):
         if multi:
             if dist.get_backend(group) == "nccl":
                 t = t.to(torch.as_tensor(values).device)
+            _count("all_reduce")
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
         return int(t.item())
 
@@ -482,10 +592,15 @@ def shared_percentile(values, q_percent, sub=None, select=None, group=None):
     rank = prefix = nan_total = cnt_final = N = 0
     same = False
     for p in range(3):
-        h, nan = select.hist(values, p, prefix)
+        h, nan = first_hist if (p == 0 and first_hist is not None) else select.hist(values, p, prefix)
         if p == 0:
-            # the first exchange also carries every rank's value count and NaN count: one all-reduce, not three
-            hx = allsum(np.concatenate([np.asarray(h, dtype=np.int64), [int(nan), n_local]]))
+            # the first exchange also carries every rank's value count and NaN count (and the caller's words): one
+            # all-reduce, not three
+            hx = allsum(np.concatenate([np.asarray(h, dtype=np.int64), [int(nan), n_local], ride]))
+            nh = len(hx) - len(ride)
+            ride_sum, hx = hx[nh:], hx[:nh]
+            if callable(sub):
+                sub = sub(ride_sum)
             h, nan_total, N = hx[:-2], int(hx[-2]), int(hx[-1])
             if N == 0:
                 raise IndexError("index -1 is out of bounds for axis 0 with size 0")     # what np.percentile raises
@@ -541,7 +656,7 @@ class HipMeanShard:
         return self._sh.walk(sum_in, total_n)
 
 
-def sharded_centroid(own_rows, total_n, shard=None, group=None, timings=None):
+def sharded_centroid(own_rows, total_n, shard=None, group=None, timings=None, broadcast=True):
     """np.mean(concatenation of every rank's rows in RANK order, axis=0) of float32 [n_r,3] shards, bit for bit:
     numpy's sum is sequential per column, so the three running float32 sums travel down the line of ranks
     (12 bytes per hop, one send/recv each) and the last rank divides by float32(total_n) and broadcasts.  Every rank
@@ -553,8 +668,7 @@ def sharded_centroid(own_rows, total_n, shard=None, group=None, timings=None):
         return np.full(3, np.nan, dtype=np.float32)
     shard = shard or HipMeanShard(own_rows)
     _mark(timings, "c.tables_enqueued")
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-    if not multi:
+    if not _multi(group):
         return torch.as_tensor(shard.walk(None, int(total_n))).cpu().numpy().astype(np.float32)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     wdev = getattr(shard, "device", torch.device("cpu"))
@@ -562,6 +676,7 @@ def sharded_centroid(own_rows, total_n, shard=None, group=None, timings=None):
     sum_in = None
     if rank > 0:
         buf = torch.empty(3, dtype=torch.float32, device=comm_dev)
+        _count("recv")
         dist.recv(buf, src=dist.get_global_rank(group, rank - 1) if group is not None else rank - 1, group=group)
         _mark(timings, "c.recv")
         sum_in = buf.to(wdev)
@@ -569,9 +684,13 @@ def sharded_centroid(own_rows, total_n, shard=None, group=None, timings=None):
     out = torch.as_tensor(shard.walk(sum_in, int(total_n) if last else 0)).to(comm_dev, torch.float32)
     _mark(timings, "c.walk_done")
     if not last:
+        _count("send")
         dist.send(out, dst=dist.get_global_rank(group, rank + 1) if group is not None else rank + 1, group=group)
         out = torch.empty(3, dtype=torch.float32, device=comm_dev)
+    if not broadcast:
+        return out.cpu().numpy().astype(np.float32) if last else None
     src = dist.get_global_rank(group, world - 1) if group is not None else world - 1
+    _count("broadcast")
     dist.broadcast(out, src=src, group=group)
     _mark(timings, "c.bcast")
     return out.cpu().numpy().astype(np.float32)
@@ -582,8 +701,7 @@ def global_rows(local_row, n_own, group=None):
     each other in rank order, so the base is the exclusive prefix of n_own over the ranks (one all_gather of one
     integer per rank - what reading the LAS headers of a tile stream gives).  Returns (rows int64, total rows)."""
     group = _pg(group)
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-    if not multi:
+    if not _multi(group):
         return local_row, int(n_own)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = local_row.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
@@ -619,34 +737,53 @@ def tiled_step(tile, tile_rows, own, total_n, x_lo, x_hi, eps=8.0, min_samples=8
     own_rows = tile[a:b]                                   # a view: the owned rows are one slice of the tile
     _mark(timings, "start")
     shard = HipMeanShard(own_rows, want_zcol=True)         # tables + a contiguous z column in one pass over the rows
-    centroid = sharded_centroid(own_rows, total_n, shard=shard, group=group, timings=timings)
+    multi = _multi(group)
+    # Collectives of one step (one rank per GPU): the two hops of the centroid chain (recv, send), ONE all-reduce
+    # that carries the first histogram of the percentile, the value / NaN counts AND the centroid (the last rank's
+    # float32 bits, zeros elsewhere: a broadcast for free), the two further histogram passes, and ONE all_gather
+    # for the cluster tables, both strips and the survivor counts.  The fallback decision (< min_keep survivors at
+    # the ordinary offset) is taken from the counts that ride in that last exchange: the filter and the fit run at
+    # the ordinary offset first and are repeated at the fallback offset only in that (rare) case.
+    select = HipSelect()
+    hist0 = select.hist(shard.zcol, 0, 0)                  # does not depend on the centroid: computed beside the chain
+    mine = sharded_centroid(own_rows, total_n, shard=shard, group=group, timings=timings, broadcast=not multi)
     _mark(timings, "centroid")
-    base = shared_percentile(shard.zcol, pct, sub=centroid[2], group=group)
-    _mark(timings, "percentile")
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    cen = {}
 
-    def filtered(off):
+    def take_centroid(words):                              # the summed ride-along words: the last rank's centroid bits
+        cen["c"] = np.asarray(words, dtype=np.int64).astype(np.uint32).view(np.float32).copy()
+        return cen["c"][2]
+
+    if multi:
+        bits = (np.zeros(3, dtype=np.int64) if mine is None
+                else np.asarray(mine, dtype=np.float32).view(np.uint32).astype(np.int64))
+        base = shared_percentile(shard.zcol, pct, sub=take_centroid, select=select, group=group, ride=bits,
+                                 first_hist=hist0)
+        centroid = cen["c"]
+    else:
+        centroid = mine
+        base = shared_percentile(shard.zcol, pct, sub=centroid[2], select=select, group=group, first_hist=hist0)
+    _mark(timings, "percentile")
+    cx = float(centroid[0])                                # the kept points are centred: so are the edges
+
+    def attempt(off):
         thr = np.float32(base + np.float32(off))
         kept = ops.filter_gt(tile, centroid, thr, want_index=True)
         loc = kept["index"].long()
         own_k = (loc >= a) & (loc < b)
-        cnt = torch.tensor([int(own_k.sum())], dtype=torch.int64)
-        if multi:
-            if dist.get_backend(group) == "nccl":
-                cnt = cnt.to(tile.device)
-            dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
-        return thr, kept, loc, own_k, int(cnt.item())
+        mine_kept = int(own_k.sum())
+        t1 = time.perf_counter()
+        _mark(timings, "filter")
+        labels, K, words = cluster_tiled(kept["points"], tile_rows[loc], own_k, float(x_lo) - cx, float(x_hi) - cx,
+                                         eps, min_samples, halo=halo, group=group, timings=timings,
+                                         extra=(mine_kept,))
+        return thr, kept, loc, own_k, int(np.asarray(words)[:, 0].sum()), labels, K, t1
 
-    thr, kept, loc, own_k, survivors = filtered(offset)
+    thr, kept, loc, own_k, survivors, labels, K, t1 = attempt(offset)
     used_fallback = False
     if survivors < int(min_keep):                          # utils/tower_extraction.py:87-89, on the WHOLE cloud's count
-        thr, kept, loc, own_k, survivors = filtered(fallback_offset)
+        thr, kept, loc, own_k, survivors, labels, K, t1 = attempt(fallback_offset)
         used_fallback = True
-    t1 = time.perf_counter()
-    _mark(timings, "filter")
-    cx = float(centroid[0])                                # the kept points are centred: so are the edges
-    labels, K = cluster_tiled(kept["points"], tile_rows[loc], own_k, float(x_lo) - cx, float(x_hi) - cx, eps,
-                              min_samples, halo=halo, group=group, timings=timings)
     if timings is not None and "trace" not in timings:
         timings["filter_ms"] = timings.get("filter_ms", 0.0) + 1e3 * (t1 - t0)
     return dict(centroid=centroid, threshold=thr, used_fallback=used_fallback, points=kept["points"],

@@ -6,8 +6,16 @@ GPU by ``pch_voxel_downsample_f64`` (all chunks in one pass, each with its own g
 cross-chunk duplicates kept - exactly the reference's chunk loop); LAS decode/encode
 arithmetic (X*scale+offset, rint((v-offset)/scale)) also runs on the device.
 
-Output order differs from Open3D's (hash-map iteration order there, sorted by voxel index
-here); the set of output points is the same.
+Output order differs from Open3D's (hash-map iteration order there; here: chunks in file order, inside a
+chunk coarse grid cells in index order and the voxels of a cell in the order of their first points -
+deterministic); the set of output points per chunk is the same.
+
+Hand-off to tower extraction (pyGUI_towers_test.py:344-368 calls the two back to back): the int32 records of the
+output file stay registered on the device (pointcloudhookup_amd/resident.py), so ``extract_towers`` on that path
+does not read the file back.  ``ASYNC_WRITE`` (env PCH_ASYNC_LAS_WRITE=1, default off) additionally moves the
+file write to a background thread: ``run_voxel_downsampling`` returns once the records exist, ``extract_towers``
+joins the writer before it returns.  Off by default because an unchanged caller may open the file with a reader
+of its own (the GUI's laspy.read) as soon as this function returns.
 """
 from __future__ import annotations
 
@@ -17,6 +25,7 @@ from typing import Callable
 import numpy as np
 
 DEVICE = os.environ.get("PCH_DEVICE", "cuda:0")
+ASYNC_WRITE = os.environ.get("PCH_ASYNC_LAS_WRITE", "0") == "1"
 
 
 def process_chunk(points_chunk, voxel_size):
@@ -82,9 +91,36 @@ def run_voxel_downsampling(
             progress_callback(int((end / total_points) * 100))
 
     clock.mark("per-chunk callbacks")
-    _las.write_device(output_path, _las.LasHeader(point_format=hdr.point_format, version=hdr.version,
-                                                  scales=hdr.scales, offsets=hdr.offsets), out_XYZ)
-    clock.mark("write LAS (encode, D2H, file)")
+    from .. import resident
+    header = _las.LasHeader(point_format=hdr.point_format, version=hdr.version, scales=hdr.scales,
+                            offsets=hdr.offsets, point_count=n_out)
+    entry = resident.Entry(output_path, header, out_XYZ)
+
+    def write_file():
+        try:
+            _las.write_device(output_path, header, out_XYZ)
+            entry.stamp_now()
+        except BaseException as e:                                     # surfaces in extract_towers / at the join
+            entry.error = e
+
+    if ASYNC_WRITE and resident.enabled():
+        import threading
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))              # the records are final behind this point
+
+        def in_background():
+            with torch.cuda.device(dev), torch.cuda.stream(side):
+                write_file()
+
+        entry.writer = threading.Thread(target=in_background, name="pch-las-writer")   # not a daemon: the
+        entry.writer.start()                                           # interpreter waits for the file at exit
+        clock.mark("write LAS (encode, D2H, file): started in the background", sync=False)
+    else:
+        write_file()
+        if entry.error is not None:
+            raise entry.error
+        clock.mark("write LAS (encode, D2H, file)")
+    resident.register(entry)
     ops.release_workspace()
 
     if log_callback:

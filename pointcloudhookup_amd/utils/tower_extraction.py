@@ -51,7 +51,27 @@ def extract_towers(
         min_width=8,
         duplicate_threshold=30.0
 ):
-    """Tower extraction with the reference's call surface (utils/tower_extraction.py:20-240)."""
+    """Tower extraction with the reference's call surface (utils/tower_extraction.py:20-240).
+
+    When ``input_las_path`` is the file ``run_voxel_downsampling`` has just written in this process, its records
+    are still on the device (pointcloudhookup_amd/resident.py) and are taken instead of reading the file back -
+    provided the file on disk still is the one that was written; a background writer is joined before this
+    function returns, and if the file turns out to have been changed meanwhile the extraction is redone from it."""
+    from .. import resident
+    args = (progress_callback, log_callback, eps, min_points, aspect_ratio_threshold, min_height, max_width,
+            min_width, duplicate_threshold)
+    entry = resident.take(input_las_path)       # (a background writer may not even have created the file yet)
+    if entry is None:
+        return _extract(input_las_path, None, *args)
+    try:
+        towers = _extract(input_las_path, entry, *args)
+    finally:
+        same = resident.settle(entry)
+    return towers if same else _extract(input_las_path, None, *args)
+
+
+def _extract(input_las_path, resident_entry, progress_callback, log_callback, eps, min_points,
+             aspect_ratio_threshold, min_height, max_width, min_width, duplicate_threshold):
     tower_obbs = []
     tower_rows = []
 
@@ -77,8 +97,12 @@ def extract_towers(
             from .. import obb as _obb
             _obb.prestart()                # the box workers import scipy while the file is being read
         dev = torch.device(DEVICE)
-        hdr, XYZ = _las.read_device(input_las_path, dev)               # records decoded on the GPU
-        clock.mark("read LAS -> device int32 (file, H2D, decode)")
+        if resident_entry is not None and resident_entry.records is not None:
+            hdr, XYZ = resident_entry.header, resident_entry.records   # written by this process a moment ago
+            clock.mark("LAS records taken from the device (no file read)")
+        else:
+            hdr, XYZ = _las.read_device(input_las_path, dev)           # records decoded on the GPU
+            clock.mark("read LAS -> device int32 (file, H2D, decode)")
         raw = ops.cast_f32(ops.las_scale(XYZ, hdr.scales, hdr.offsets))
         del XYZ
         clock.mark("int32 -> float64 -> float32")
@@ -143,6 +167,18 @@ def extract_towers(
     centroid = gf["centroid"]
 
     las_seconds = [0.0]
+    las_jobs = {}
+
+    def prepare(accepted):
+        """the per-tower LAS files (reference :205-207) are written by a few threads while the accept / de-dup log
+        is replayed; each tower's own messages are logged where the reference logs them"""
+        if len(accepted) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            ex = ThreadPoolExecutor(max_workers=min(8, len(accepted)), thread_name_prefix="pch-tower-las")
+            for t in accepted:
+                las_jobs[t["label"]] = ex.submit(_save_tower_las_msgs, t["points"] + centroid, header_info,
+                                                 output_dir / f"tower_{t['label']}.las")
+            ex.shutdown(wait=False)
 
     def accept(t):
         label = t["label"]
@@ -153,16 +189,21 @@ def extract_towers(
                            "海拔高度": t["center"][2], "杆塔高度": t["height"],
                            "北方向偏角": t["north_angle"], "宽度": t["width"],
                            "长宽比": t["aspect_ratio"]})
-        original_points = t["points"] + centroid                       # float32, reference :205
         t_las = time.perf_counter()
-        _save_tower_las(original_points, None, header_info, output_dir / f"tower_{label}.las", log)
+        if label in las_jobs:
+            for msg in las_jobs.pop(label).result():
+                log(msg)
+        else:
+            original_points = t["points"] + centroid                   # float32, reference :205
+            _save_tower_las(original_points, None, header_info, output_dir / f"tower_{label}.las", log)
         las_seconds[0] += time.perf_counter() - t_las
         log(f"✅ 杆塔{label}: {t['height']:.1f}m高 | {t['width']:.1f}m宽 | 中心坐标{t['center']}")
         progress(75 + int(15 * (label + 1) / max(k, 1)))
 
     clock.mark("per-chunk callbacks")
     pipeline.tower_table(clusters, aspect_ratio_threshold, min_height, max_width, min_width,
-                         duplicate_threshold, OBB_EXTENT_ORDER, log=log, on_accept=accept, obb_mode=OBB_MODE)
+                         duplicate_threshold, OBB_EXTENT_ORDER, log=log, on_accept=accept, obb_mode=OBB_MODE,
+                         prepare=prepare)
     clock.mark("tower boxes + accept / de-dup (D1-D3)")
     clock.move("tower boxes + accept / de-dup (D1-D3)", "per-tower LAS files", las_seconds[0])
 
@@ -214,9 +255,8 @@ def _rejected_chunks(filtered, ops):
     return out
 
 
-def _save_tower_las(points, colors, header_info, output_path, log_callback=None):
-    """Per-tower LAS with the input's point format / version / scales / offsets
-    (reference :243-262); coordinates are re-quantised like laspy's x/y/z setters."""
+def _save_tower_las_msgs(points, header_info, output_path):
+    """writes the file, returns the messages the reference logs for it"""
     try:
         from .. import las as _las
         pts = np.asarray(points)
@@ -225,11 +265,17 @@ def _save_tower_las(points, colors, header_info, output_path, log_callback=None)
         hdr = _las.LasHeader(point_format=header_info["point_format"], version=header_info["version"],
                              scales=sc, offsets=of)
         _las.write(str(output_path), hdr, XYZ)
-        if log_callback:
-            log_callback(f"保存成功：{output_path}")
+        return [f"保存成功：{output_path}"]
     except Exception as e:
+        return [f"⚠️ 保存失败 {output_path}: {str(e)}"]
+
+
+def _save_tower_las(points, colors, header_info, output_path, log_callback=None):
+    """Per-tower LAS with the input's point format / version / scales / offsets
+    (reference :243-262); coordinates are re-quantised like laspy's x/y/z setters."""
+    for msg in _save_tower_las_msgs(points, header_info, output_path):
         if log_callback:
-            log_callback(f"⚠️ 保存失败 {output_path}: {str(e)}")
+            log_callback(msg)
 
 
 def create_obb_geometries(tower_obbs):

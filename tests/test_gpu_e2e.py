@@ -40,14 +40,19 @@ def test_run_voxel_downsampling_dropin(cuda, config1_las):
     ridx, rmean, rcnt, roffs = ovx.voxel_down_sample_chunked(xyz, 0.1, 500000)
     got = las.read(out)
     ref_XYZ = np.stack([ovx.las_unscale(rmean[:, a], SCALES[a], OFFSETS[a]) for a in range(3)], axis=1)
-    np.testing.assert_array_equal(got.XYZ, ref_XYZ)                 # same voxel set, same order
+    assert len(got.XYZ) == len(ref_XYZ)
+    for c in range(len(roffs) - 1):                                 # per chunk the same multiset of records (the order
+        a, b = int(roffs[c]), int(roffs[c + 1])                     # inside a chunk is unspecified, as with Open3D)
+        np.testing.assert_array_equal(got.XYZ[a:b][np.lexsort(got.XYZ[a:b].T[::-1])],
+                                      ref_XYZ[a:b][np.lexsort(ref_XYZ[a:b].T[::-1])])
     assert got.header.point_format == 3 and tuple(got.header.version) == (1, 2)
     np.testing.assert_array_equal(got.header.scales, SCALES)
     assert prog == [50, 100]
     assert logs[0] == "📂 原始点数: 1000000" and logs[-2] == f"✅ 下采样完成，输出点数: {len(rcnt)}"
     assert logs[2] == "✅ 已完成第1块：500000 点"
     m = process_chunk(xyz[:20000], 0.5)
-    np.testing.assert_array_equal(m, ovx.voxel_down_sample(xyz[:20000], 0.5)[1])
+    want = ovx.voxel_down_sample(xyz[:20000], 0.5)[1]
+    np.testing.assert_array_equal(m[np.lexsort(m.T[::-1])], want[np.lexsort(want.T[::-1])])
 
 
 def test_sampling_cli_twin(cuda, config1_las, capsys):
@@ -121,9 +126,10 @@ def test_config2_voxel_then_cluster_properties(cuda, oracle_clib):
     host = xyz[:500000].cpu().numpy()
     ridx, rmean, rcnt = ovx.voxel_down_sample(host, 0.2)            # first chunk against the oracle
     m0 = int(offs[1])
-    np.testing.assert_array_equal(idx[:m0].cpu().numpy(), ridx)
-    np.testing.assert_array_equal(mean[:m0].cpu().numpy(), rmean)
-    np.testing.assert_array_equal(cnt[:m0].cpu().numpy(), rcnt)
+    gi, gm, gc = ovx.canonical(idx[:m0].cpu().numpy(), mean[:m0].cpu().numpy(), cnt[:m0].cpu().numpy(), [0, m0])
+    np.testing.assert_array_equal(gi, ridx)                         # the same set of voxels (order inside a chunk
+    np.testing.assert_array_equal(gm, rmean)                        # is the library's own, as it is Open3D's)
+    np.testing.assert_array_equal(gc, rcnt)
     # idempotence on one chunk: each mean lies in its own voxel
     i2, m2, c2, _ = ops.voxel_downsample(mean[:m0].contiguous(), 0.2, 0)
     assert i2.shape[0] <= m0
@@ -247,8 +253,8 @@ def test_bench_tiled_mode_equals_the_single_gpu_run(cuda, world):
     """BASELINE config 4 end to end through bench.py's own launcher: `python bench.py --gpus W --mode tiled --verify`
     starts W ranks (sharing this one GPU, exchange over gloo - RCCL refuses two ranks on one device), every rank
     generates ONLY its x-tile + halo of a 12 M-point strip corridor at EPSG scale, and tiles.tiled_step (chained
-    float32 centroid, percentile across the ranks, per-tile filter, global DBSCAN per tile, two fixed-capacity
-    all_gathers, relabel) must reproduce the single-GPU run of the whole cloud: centroid and threshold bit for bit,
+    float32 centroid, percentile across the ranks, per-tile filter, global DBSCAN per tile, one fixed-capacity
+    all_gather, relabel) must reproduce the single-GPU run of the whole cloud: centroid and threshold bit for bit,
     every owned label, every kept row owned exactly once.  Towers sit on the strip edges, hence on the tile edges."""
     import json
     import subprocess
@@ -267,6 +273,40 @@ def test_bench_tiled_mode_equals_the_single_gpu_run(cuda, world):
     assert t["ranks_seen"] == world and out["n_gpus"] == world and t["points_total"] == 12_000_000
     assert t["clusters"] >= 3 and t["kept_points"] > 100_000
     assert set(t["phase_ms_max_over_ranks"]) == {"centroid_chain+threshold+filter", "local_fit", "reconciliation"}
+    # rank 0 of W: no recv; one send unless it is also the last; three all_reduces, ONE all_gather: at most six
+    calls = t["collectives_per_step_rank0"]
+    if world > 1:
+        assert calls == {"send": 1, "all_reduce": 3, "all_gather": 1}, calls
+
+
+def test_tiled_step_over_rccl_with_forced_collectives(cuda):
+    """PCH_TILES_FORCE_COLLECTIVES=1: a world of one rank brings a one-rank NCCL (= RCCL) group up on this GPU and
+    every function of tiles.py takes its multi-rank branch - the all_reduce that carries the first histogram, the
+    counts and the centroid bits, the two further histogram all_reduces and the all_gather of the int64 blocks
+    (cluster table, both strips, survivor counts) really run on device tensors over RCCL; the point-to-point hops of
+    the centroid chain are the only calls a single rank cannot make.  The result must still be the single-GPU run's
+    (centroid and threshold bits, every label), and a step issues at most six collectives."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PCH_TILES_FORCE_COLLECTIVES="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PCH_DIST_BACKEND",
+              "PCH_BENCH_SINGLE_DEVICE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "tiled",
+                        "--points", "12000000", "--steps", "3", "--warmup", "1", "--verify"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    t = out["tiled"]
+    assert t["verified_against_single_gpu_run"] is True
+    assert t["backend"] == "nccl" and t["forced_collectives"] is True
+    calls = t["collectives_per_step_rank0"]
+    assert calls.get("all_reduce") == 3 and calls.get("all_gather") == 1, calls
+    assert t["collectives_per_step_rank0_total"] <= 6
+    print("[forced collectives over RCCL]", json.dumps({k: t[k] for k in (
+        "backend", "collectives_per_step_rank0", "ms_per_step", "phase_ms_max_over_ranks", "clusters", "kept_points")}))
 
 
 def test_rccl_probe_failure_degrades_to_gloo(cuda):
@@ -400,9 +440,12 @@ def test_lookback_wait_is_bounded(cuda):
     rc = L.pch_selftest_lookback_timeout(50, scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream)
     dt = time.perf_counter() - t0
     assert rc == _lib.PCH_ERR_TIMEOUT, L.pch_last_error()
-    assert 0.04 < dt < 1.5, dt                                        # two waiters, 50 ms each at most, not 4 s
+    assert 0.04 < dt < 1.5, dt                                        # one waiter runs out its 50 ms, five more stop on
+                                                                      # its poisoned word: not 6 x 50 ms, not 4 s
+    # the self-test also checked the published count word: six failed tiles mark it with the (idempotent) sign bit,
+    # so it reads negative however many tiles fail - a sum of -2^62 per tile wrapped to 0 at four
     with pytest.raises(_lib.PchError, match="PCH_ERR_TIMEOUT"):
-        _lib.check_count(-(1 << 62) + 5, "x")
+        _lib.check_count(-(1 << 63) + 5, "x")
     assert _lib.check_count(7, "x") == 7
     # and the data path is unaffected: an ordinary filter still gives its count
     raw = synth.corridor_torch(300_000, seed=synth.SEED0 + 12, kind="corridor", offset=True, device=cuda,
@@ -447,3 +490,70 @@ def tiles_shared_threshold(raw, gf):
     from pointcloudhookup_amd import tiles
     base = tiles.shared_percentile(raw[:, 2], 25.0, sub=gf["centroid"][2])
     return np.float32(base + np.float32(3.0))
+
+
+def _towers_equal(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert set(x) == set(y)
+        for k in x:
+            assert np.array_equal(np.asarray(x[k]), np.asarray(y[k])), k
+
+
+@pytest.mark.parametrize("async_write", [False, True])
+def test_voxel_then_towers_hand_off_without_rereading_the_file(cuda, config1_las, tmp_path, monkeypatch, async_write):
+    """run_voxel_downsampling leaves the records of its output file registered on the device; extract_towers on
+    that path takes them instead of reading the file back (pointcloudhookup_amd/resident.py) - with the writer in
+    the foreground (default) or in the background.  Either way the file on disk is byte for byte what the plain path
+    writes, and the towers equal those of a run that reads the file: also after the file was touched (stamp
+    mismatch -> file), and with the hand-off switched off."""
+    import hashlib
+    import time
+    from pointcloudhookup_amd import las as _las, resident, stages
+    from pointcloudhookup_amd.ui import import_PC
+    from pointcloudhookup_amd.utils import tower_extraction as te
+    path, XYZ, xyz, d = config1_las
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(import_PC, "ASYNC_WRITE", async_write)
+    sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()
+    # the plain path: hand-off off, file read back
+    monkeypatch.setenv("PCH_RESIDENT_HANDOFF", "0")
+    plain = str(tmp_path / "plain" / "point_2.las")
+    import_PC.run_voxel_downsampling(path, plain, 0.1, 500000)
+    want_sha = sha(plain)
+    want = te.extract_towers(plain, log_callback=lambda m: None)
+    assert len(want) >= 1
+    monkeypatch.setenv("PCH_RESIDENT_HANDOFF", "1")
+    reads = []
+    real_read = _las.read_device
+    monkeypatch.setattr(_las, "read_device", lambda p, dev: (reads.append(p), real_read(p, dev))[1])
+    # 1. handed over on the device: no read of the intermediate file
+    out = str(tmp_path / "output" / "point_2.las")
+    import_PC.run_voxel_downsampling(path, out, 0.1, 500000)
+    n_reads = len(reads)                                               # the input file was read, nothing else
+    logs = []
+    got = te.extract_towers(out, log_callback=logs.append)
+    assert len(reads) == n_reads, "extract_towers read the file although its records were resident"
+    assert sha(out) == want_sha
+    _towers_equal(want, got)
+    # 2. consumed: a second call reads the file
+    _towers_equal(want, te.extract_towers(out, log_callback=lambda m: None))
+    assert len(reads) == n_reads + 1
+    # 3. touched between the two calls: the stamp no longer matches -> the file is read
+    import_PC.run_voxel_downsampling(path, out, 0.1, 500000)
+    resident.wait_for_writers()
+    n_reads = len(reads)
+    st = os.stat(out)
+    os.utime(out, ns=(st.st_atime_ns, st.st_mtime_ns + 1_000_000))
+    _towers_equal(want, te.extract_towers(out, log_callback=lambda m: None))
+    assert len(reads) == n_reads + 1
+    # 4. another path that merely holds the same bytes is not the registered file
+    import_PC.run_voxel_downsampling(path, out, 0.1, 500000)
+    resident.wait_for_writers()
+    n_reads = len(reads)
+    other = str(tmp_path / "copy.las")
+    with open(other, "wb") as f:
+        f.write(open(out, "rb").read())
+    _towers_equal(want, te.extract_towers(other, log_callback=lambda m: None))
+    assert len(reads) == n_reads + 1
+    assert resident.take(out) is not None                              # still registered (and now consumed)

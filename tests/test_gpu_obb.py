@@ -162,3 +162,43 @@ def test_shell_argument_checks_and_small_inputs(cuda):
     dP, perm2, offs2, clusters = _grouped([same, seg], rng, offset=(0.0, 0.0, 0.0), noise=10)
     keep = ops.obb_shell(dP, perm2, offs2, 2).cpu().numpy()
     assert keep.all()
+
+
+def test_tower_table_through_the_pool_is_the_serial_loop_and_may_run_beside_the_next_tile(cuda):
+    """Exact mode: the clustered points travel once into a shared registered buffer, worker processes box them.
+    The result must be the serial loop's bit for bit (every cluster through obb.bounding_box_oriented in this
+    process), for the blocking call and for tower_table_async with the next tile clustered meanwhile."""
+    from pointcloudhookup_amd import synth
+    tile = synth.corridor_torch(3_000_000, seed=synth.SEED0 + 4, kind="corridor", offset=True, towers=12,
+                                dtype=torch.float32)
+    cl = pipeline.cluster_points(tile)
+    k = int(cl["nclusters"])
+    offs = cl["offsets"].cpu().numpy()
+    host = cl["ground"]["points"].index_select(0, cl["perm"][: int(offs[k])].long()).cpu().numpy()
+    serial = [obb._boxed((host[offs[i]:offs[i + 1]], "unsorted")) for i in range(k)]
+    want = [t for kind, t in pipeline._accept(serial, cl["ground"]["centroid"], 0.8, 15.0, 50.0, 8, 30.0)
+            if kind == "tower"]
+    assert len(want) >= 2
+    tm, logs, seen = {}, [], []
+    got = pipeline.tower_table(cl, log=logs.append, on_accept=seen.append, timings=tm,
+                               prepare=lambda acc: seen.append(len(acc)))
+    assert seen[0] == len(got) and seen[1:] == got                       # prepare first, then every tower in order
+    assert tm["workers"] >= 1 and tm["clustered_points"] == int(offs[k]) and tm["boxes_worker_cpu_ms"] > 0
+
+    def same(a, b):
+        assert [t["label"] for t in a] == [t["label"] for t in b]
+        for x, y in zip(a, b):
+            for key in ("center", "rotation", "extent"):
+                assert np.array_equal(np.asarray(x[key]), np.asarray(y[key])), key
+            assert x["north_angle"] == y["north_angle"]
+            assert np.array_equal(x["points"], host[offs[x["label"]]:offs[x["label"] + 1]])
+
+    same(want, got)
+    # in flight beside the next tile's device work; two tables at once use two buffers
+    j1 = pipeline.tower_table_async(cl)
+    cl2 = pipeline.cluster_points(tile)
+    j2 = pipeline.tower_table_async(cl2)
+    del cl2
+    same(want, j1.result(120))
+    same(want, j2.result(120))
+    assert j1.timings["workers"] >= 1

@@ -32,10 +32,18 @@ def test_voxel_matches_oracle(cuda, n, voxel, chunk):
     idx, mean, count, offs = ops.voxel_downsample(_dev(pts, cuda), voxel, chunk)
     ridx, rmean, rcount, roffs = ovx.voxel_down_sample_chunked(pts, voxel, chunk if chunk else n)
     assert idx.shape[0] == ridx.shape[0]
-    np.testing.assert_array_equal(offs.cpu().numpy(), roffs)
-    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)          # voxel indices bit exact
-    np.testing.assert_array_equal(count.cpu().numpy(), rcount)
-    np.testing.assert_array_equal(mean.cpu().numpy(), rmean)        # in-order f64 sums: bit exact
+    _voxel_sets_equal(idx, mean, count, offs, ridx, rmean, rcount, roffs)
+
+
+def _voxel_sets_equal(idx, mean, count, offs, ridx, rmean, rcount, roffs):
+    """stage-A parity: per chunk the same SET of (voxel index, mean, count) - the library's order
+    inside a chunk is its own (Open3D's is unordered_map order), so both sides are compared sorted by index"""
+    offs = offs.cpu().numpy()
+    np.testing.assert_array_equal(offs, roffs)
+    gi, gm, gc = ovx.canonical(idx.cpu().numpy(), mean.cpu().numpy(), count.cpu().numpy(), offs)
+    np.testing.assert_array_equal(gi, ridx)                          # voxel indices bit exact
+    np.testing.assert_array_equal(gc, rcount)
+    np.testing.assert_array_equal(gm.view(np.uint64), rmean.view(np.uint64))   # in-order f64 sums: bit exact
 
 
 @pytest.mark.parametrize("case", ["dense_core", "one_voxel_20000", "wide_keys_u64", "huge_keys_general",
@@ -65,19 +73,14 @@ def test_voxel_paths_match_oracle(cuda, case):
         pts, voxel, chunk = np.tile(OFFSET + [1.0, 2.0, 3.0], (9000, 1)), 0.1, 4000
     idx, mean, count, offs = ops.voxel_downsample(_dev(pts, cuda), voxel, chunk)
     ridx, rmean, rcount, roffs = ovx.voxel_down_sample_chunked(pts, voxel, chunk if chunk else len(pts))
-    np.testing.assert_array_equal(offs.cpu().numpy(), roffs)
-    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
-    np.testing.assert_array_equal(count.cpu().numpy(), rcount)
-    np.testing.assert_array_equal(mean.cpu().numpy(), rmean)
+    _voxel_sets_equal(idx, mean, count, offs, ridx, rmean, rcount, roffs)
 
 
 def test_voxel_single_voxel_and_negative_coords(cuda):
     pts = np.array([[-1.0, -2.0, -3.0], [-1.01, -2.01, -3.01], [-0.99, -1.99, -2.99]])
-    idx, mean, count, _ = ops.voxel_downsample(_dev(pts, cuda), 5.0, 0)
+    idx, mean, count, offs = ops.voxel_downsample(_dev(pts, cuda), 5.0, 0)
     ridx, rmean, rcount = ovx.voxel_down_sample(pts, 5.0)
-    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
-    np.testing.assert_array_equal(mean.cpu().numpy(), rmean)
-    np.testing.assert_array_equal(count.cpu().numpy(), rcount)
+    _voxel_sets_equal(idx, mean, count, offs, ridx, rmean, rcount, np.array([0, len(rcount)]))
 
 
 def test_voxel_too_small_raises(cuda):
@@ -716,6 +719,10 @@ def test_voxel_set_is_invariant_under_permutation_within_a_chunk(cuda, seed):
     pts = rng.random((60000, 3)) * [80.0, 40.0, 12.0] + OFFSET
     a = ops.voxel_downsample(_dev(pts, cuda), 0.3, 0)
     b = ops.voxel_downsample(_dev(pts[rng.permutation(len(pts))], cuda), 0.3, 0)
+    a = [torch.from_numpy(x) for x in ovx.canonical(a[0].cpu().numpy(), a[1].cpu().numpy(), a[2].cpu().numpy(),
+                                                    a[3].cpu().numpy())]
+    b = [torch.from_numpy(x) for x in ovx.canonical(b[0].cpu().numpy(), b[1].cpu().numpy(), b[2].cpu().numpy(),
+                                                    b[3].cpu().numpy())]
     np.testing.assert_array_equal(a[0].cpu().numpy(), b[0].cpu().numpy())
     np.testing.assert_array_equal(a[2].cpu().numpy(), b[2].cpu().numpy())
     np.testing.assert_allclose(a[1].cpu().numpy(), b[1].cpu().numpy(), rtol=0, atol=1e-8)

@@ -391,17 +391,18 @@ class OracleFit:                                       # CPU stand-in for tiles.
 take, own = tiles.tile_select(X[:, 0], edges, rank, 2 * EPS)
 rows = np.flatnonzero(take)
 pts = X[rows]
-tiles.TILED_PCAP = 8                                   # a pair buffer that overflows: the exchange must repeat once
-tiles.TILED_KCAP, tiles.TILED_LCAP = 4, 1              # ... and so must the cluster table and the link block
+tiles.TILED_PCAP = 2                                   # a pair buffer that overflows: the exchange must repeat once
+tiles.TILED_KCAP = 4                                   # ... and so must the cluster table
 if use_gpu:
     dev = torch.device("cuda:0")
-    labels, K = tiles.cluster_tiled(torch.from_numpy(pts).to(dev), torch.from_numpy(rows), own[rows],
-                                    edges[rank], edges[rank + 1], EPS, MS)
+    labels, K, words = tiles.cluster_tiled(torch.from_numpy(pts).to(dev), torch.from_numpy(rows), own[rows],
+                                           edges[rank], edges[rank + 1], EPS, MS, extra=(rank + 5,))
     labels = labels.cpu().numpy()
 else:
-    labels, K = tiles.cluster_tiled(torch.from_numpy(pts), torch.from_numpy(rows), own[rows],
-                                    edges[rank], edges[rank + 1], EPS, MS, fit=OracleFit())
+    labels, K, words = tiles.cluster_tiled(torch.from_numpy(pts), torch.from_numpy(rows), own[rows],
+                                           edges[rank], edges[rank + 1], EPS, MS, fit=OracleFit(), extra=(rank + 5,))
     labels = labels.numpy()
+assert np.asarray(words)[:, 0].tolist() == [r + 5 for r in range(world)]      # the words that rode along
 want, _ = odb.dbscan_fit_c(X, EPS, MS)                 # one DBSCAN over the whole cloud
 o = own[rows]
 assert K == want.max() + 1, (K, want.max() + 1)
@@ -725,3 +726,66 @@ def test_native_search_edge_cases():
     line = np.array([[0, 0, 0], [1, 1, 0], [2, 2, 0]], dtype=np.float64)
     best, vol = ops.obb_search(line, [0, 3], np.array([[0.0, 0.0]]), [0, 1])
     assert best.tolist() == [-1] and np.isinf(vol[0])
+
+
+# ------------------------------------------------------------------ stage D1: host-only library + worker pool
+def test_host_only_obb_library_exports_its_header_and_links_no_hip_runtime():
+    """libpch_obbhost.so (include/pch_obbhost.h) is what the box workers load: same search as pch_obb_search_f64,
+    no HIP runtime behind it (a pool of dozens of workers must not open the GPU)."""
+    import ctypes as C
+    from pointcloudhookup_amd import obb, ops
+    path = os.path.join(ROOT, "pointcloudhookup_amd", "libpch_obbhost.so")
+    assert os.path.exists(path), "make -C pointcloudhookup_amd/csrc builds it"
+    header = open(os.path.join(ROOT, "include", "pch_obbhost.h")).read()
+    declared = set(re.findall(r"\b(pch_obbhost_[a-z0-9_]+)\s*\(", header))
+    nm = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    assert declared and declared <= set(re.findall(r" T (pch_obbhost_[a-z0-9_]+)", nm))
+    ldd = subprocess.run(["ldd", path], capture_output=True, text=True).stdout
+    assert "amdhip" not in ldd and "hsa-runtime" not in ldd, ldd
+    assert obb._hostlib() is not None
+    rng = np.random.default_rng(3)
+    pts = (rng.normal(size=(5000, 3)) * [3, 2, 9]).astype(np.float32)
+    verts, angles = obb.hull_candidates(pts)
+    best, vol = ops.obb_search(verts, [0, len(verts)], angles, [0, len(angles)])
+    win = obb._winners(verts, angles)
+    assert win is not None and int(best[0]) in win.tolist()
+    assert np.array_equal(win, np.flatnonzero(vol <= vol[best[0]] * (1 + obb._TIE)))
+
+
+def test_obb_pool_jobs_in_flight_shared_buffers_and_a_dead_worker():
+    """The pool behind the exact mode: tasks name slices of a shared buffer (nothing large is pickled), several
+    jobs may be in flight, buffers are recycled, and a worker that dies has its task computed in the parent."""
+    from pointcloudhookup_amd import obb
+    rng = np.random.default_rng(9)
+    clouds = [(rng.normal(size=(int(rng.integers(500, 4000)), 3)) * [3, 2, 9 + i]).astype(np.float32)
+              for i in range(12)]
+    want = [obb._boxed((c, "native:unsorted")) for c in clouds]
+    pl = obb.pool(3)
+    assert pl.size() >= 3
+
+    def job_of(arrs):
+        offs = np.cumsum([0] + [len(a) for a in arrs])
+        buf = pl.buffer(int(offs[-1]) * 12)
+        buf.array[:int(offs[-1]) * 12].view(np.float32).reshape(-1, 3)[:] = np.concatenate(arrs)
+        return buf, obb.boxes_job(buf, offs, np.float32, "unsorted")
+
+    (b1, j1), (b2, j2) = job_of(clouds[:6]), job_of(clouds[6:])      # two jobs, two buffers, in flight together
+    assert b1 is not b2
+    got = obb.job_results(j1) + obb.job_results(j2)
+    pl.release(b1)
+    pl.release(b2)
+    for (a, ea), (b, eb) in zip(want, got):
+        assert ea is None and eb is None
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert j1.worker_s > 0 and j2.worker_s > 0
+    b3 = pl.buffer(1000)
+    assert b3 in (b1, b2)                                             # recycled, not accumulated
+    pl.release(b3)
+    # kill one worker: everything is still answered, identically
+    victim = next(p for p in pl.procs if p.alive)
+    victim.proc.kill()
+    victim.proc.wait()
+    again = list(obb.boxes_of(clouds, "unsorted", workers=3))
+    for (a, ea), (b, eb) in zip(want, again):
+        assert eb is None and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert obb.usable_cpus() >= 1 and 1 <= obb.default_workers() <= max(obb.POOL_CAP, 1)

@@ -27,38 +27,24 @@ def timed(label, fn, reps=3):
     return out
 
 
-for w in (16, 8):
+ws = [int(v) for v in os.environ.get("PCH_PROBE_WORKERS", "8,16,24,32,48").split(",")]
+for w in ws:                                   # ascending: the pool only grows
     os.environ["PCH_OBB_WORKERS"] = str(w)
-    timed(f"exact, native search, {w} workers", lambda: pipeline.tower_table(cl))
-os.environ["PCH_OBB_SEARCH"] = "python"
-timed("exact, python loop, 8 workers", lambda: pipeline.tower_table(cl), reps=2)
-os.environ["PCH_OBB_SEARCH"] = "native"
+    obb.pool(w)
+    time.sleep(1.5)                            # the new workers import scipy
+    tm = {}
+    timed(f"exact, {w} workers", lambda: pipeline.tower_table(cl, timings=tm))
+    print("   split:", {k: (round(v, 2) if isinstance(v, float) else v) for k, v in tm.items()}, flush=True)
+# the stream: tables of tile k beside the device work of tile k+1
+for depth in (1, 2, 3):
+    jobs, t0 = [], time.perf_counter()
+    for _ in range(6):
+        c2 = pipeline.cluster_points(raw)
+        jobs.append(pipeline.tower_table_async(c2))
+        del c2
+        while len(jobs) > depth:
+            jobs.pop(0).result()
+    while jobs:
+        jobs.pop(0).result()
+    print(f"stream, {ws[-1]} workers, {depth} tables in flight: {(time.perf_counter() - t0) / 6 * 1e3:.1f} ms per tile", flush=True)
 timed("fast", lambda: pipeline.tower_table(cl, obb_mode="fast"))
-
-# pieces of the exact mode
-offsets = cl["offsets"].cpu().numpy()
-t = time.perf_counter()
-rows = cl["perm"][: int(offsets[K])].long()
-host = cl["ground"]["points"].index_select(0, rows).cpu().numpy()
-print(f"gather + D2H of {len(host)} points: {(time.perf_counter() - t) * 1e3:.1f} ms")
-parts = [host[offsets[i]:offsets[i + 1]] for i in range(K)]
-t = time.perf_counter()
-first = obb._per_cluster(parts, "__hull__", 8)
-print(f"qhull + candidates in 8 workers: {(time.perf_counter() - t) * 1e3:.1f} ms")
-ok = [h for h, e in first if e is None]
-vo = np.cumsum([0] + [len(h[0]) for h in ok]); ao = np.cumsum([0] + [len(h[1]) for h in ok])
-V = np.concatenate([h[0] for h in ok]); A = np.concatenate([h[1].reshape(-1, 2) for h in ok])
-t = time.perf_counter()
-best, vol = ops.obb_search(V, vo, A, ao)
-print(f"native search, {len(ok)} hulls, {len(A)} candidates: {(time.perf_counter() - t) * 1e3:.1f} ms; "
-      f"hulls with more than one candidate within 1e-9 of the best: "
-      f"{sum((vol[ao[j]:ao[j + 1]] <= vol[ao[j] + best[j]] * (1 + 1e-9)).sum() > 1 for j in range(len(ok)))}")
-t = time.perf_counter()
-for h, b in zip(ok, best):
-    obb.bounds_from_candidates(h[0], h[1], "unsorted", np.array([int(b)]))
-print(f"winner evaluation in python: {(time.perf_counter() - t) * 1e3:.1f} ms")
-# pieces of the fast mode
-t = time.perf_counter()
-keep = ops.obb_shell(cl["ground"]["points"], cl["perm"], cl["offsets"], K)
-torch.cuda.synchronize()
-print(f"obb_shell: {(time.perf_counter() - t) * 1e3:.2f} ms, kept {int(keep.sum())} of {len(keep)}")
