@@ -223,6 +223,26 @@ def run_tiled(points_total, kind, frame, rank, world, dev, steps, warmup, seed, 
     for _ in range(2):                                     # phase split on two extra steps (adds syncs: not timed above)
         step(tm)
     barrier()
+    # the dominant kernel of this rank's step, hipEvent-timed on two more steps (not timed above)
+    from pointcloudhookup_amd import ops as _ops
+    _ops.set_profiling(True)
+    for _ in range(2):
+        res_p = step()
+    barrier()
+    prof_t = sorted(((nm, ms / max(c, 1), c) for nm, ms, c in _ops.get_profile()), key=lambda r: -r[1] * r[2])
+    _ops.set_profiling(False)
+    tiled_roof = None
+    n_own_rows, nf_tile = int(own[1]) - int(own[0]), int(res_p["points"].shape[0])
+    for nm, avg_ms, _launches in prof_t:
+        b = algorithmic_bytes(nm, n_own_rows if nm.startswith("mean_") else int(tile.shape[0]), nf_tile)
+        if b and avg_ms > 0:
+            a = b / (avg_ms * 1e-3) / 1e9
+            tiled_roof = dict(kernel=nm, bound="hbm", achieved=round(a, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                              frac=round(a / HBM_PEAK_GBS, 4), traffic=None, avg_ms=round(avg_ms, 4),
+                              bytes_per_launch=int(b), rows=n_own_rows if nm.startswith("mean_") else int(tile.shape[0]),
+                              note="rank 0's tile; hipEvent time on two extra steps; no counter set for this workload")
+            break
+    del res_p
     phases = torch.tensor([elapsed, tm["filter_ms"] / 2, tm["fit_ms"] / 2, tm["reconcile_ms"] / 2,
                            float(tile.shape[0])], dtype=torch.float64)
     kept_own = torch.tensor([int(res["own"].sum())], dtype=torch.int64)
@@ -270,7 +290,8 @@ def run_tiled(points_total, kind, frame, rank, world, dev, steps, warmup, seed, 
                         f"DBSCAN(eps={EPS:g}, min_samples={MIN_POINTS}) per tile + cross-tile label reconciliation "
                         "(BASELINE configs[3] at 400 M / 8 GPUs)",
             "points_total": int(points_total), "ranks_seen": int(dist.get_world_size()) if world > 1 else 1,
-            "backend": tiles.exchange_backend(),
+            "backend": tiles.exchange_backend(), "roofline": tiled_roof,
+            "kernels_rank0": [dict(name=nm, avg_ms=round(ms, 4), launches=c // 2) for nm, ms, c in prof_t[:8]],
             "collectives_per_step_rank0": calls, "collectives_per_step_rank0_total": round(sum(calls.values()), 2),
             "forced_collectives": bool(os.environ.get("PCH_TILES_FORCE_COLLECTIVES") == "1"),
             "devices": "one GPU shared by all ranks (rehearsal)" if os.environ.get("PCH_BENCH_SINGLE_DEVICE") else "one GPU per rank",
@@ -363,8 +384,8 @@ def main():
                    "config": {"workload": res["workload"], "points_total": res["points_total"],
                               "frame": "global-offset (+437000,+3139000,+80)" if args.frame == "offset" else "local",
                               "seed": seed, "parallelism": f"x-tiles x{world}"},
-                   "tiled": res, "roofline": None, "cpu_baseline": None,
-                   "note": "roofline and cpu_baseline are carried by the default (--mode stream) line"}
+                   "tiled": res, "roofline": res.get("roofline"), "cpu_baseline": None,
+                   "note": "cpu_baseline is carried by the default (--mode stream) line"}
             print(json.dumps(out))
         if world > 1:
             dist.destroy_process_group()
@@ -522,9 +543,19 @@ def main():
                    and algorithmic_bytes(r[0], N, NF)), None)
     tr_path = os.path.join(ROOT, "profiles", "traffic.json")   # PMC passes, see profiles/README.md
     step_traffic = None
+    traffic_dropped = None
     if os.path.exists(tr_path):
         try:
             tr = json.load(open(tr_path)).get("workloads", {}).get(f"{args.kind}/{args.frame}/{N}")
+            sys.path.insert(0, os.path.join(ROOT, "profiles"))
+            from stamp import csrc_sha
+            here_sha = csrc_sha()
+            if tr and tr.get("csrc_sha") != here_sha:
+                # counters of OTHER kernel sources: never paired with this run's times
+                traffic_dropped = (f"profiles/traffic.json[{args.kind}/{args.frame}/{N}] (set {tr.get('source')}) was collected "
+                                   f"on kernel sources {tr.get('csrc_sha')}, this run is {here_sha}: every counter-based "
+                                   "figure (traffic, frac_traffic, valu_issue_frac_measured, step_traffic) is left out")
+                tr = None
             for r in (roofline, knn, stream):     # counters of the SAME workload (kind / frame / points) only
                 if r and tr and r["kernel"] in tr.get("kernels", {}):
                     r["traffic"] = tr["kernels"][r["kernel"]]
@@ -575,6 +606,7 @@ def main():
                          ms_per_step=round(r[3], 4)) for r in kernels[:12]],
         "knn_cell_occupancy": occ,
         "step_traffic": step_traffic,
+        "counter_figures_dropped": traffic_dropped,
         "tiled": tiled_res,
     }
 
@@ -604,6 +636,33 @@ def main():
             except Exception as e:
                 others[f"{kind}/{frame}"] = {"error": str(e)}
         out["other_workloads"] = others
+
+        # the same step with the tile handed over as a HOST buffer: pinned host tile -> device -> one step (BASELINE.md
+        # section 3, "Mpts/s (GPU incl. H2D)"); never the headline value
+        try:
+            host_tile = torch.empty((N, 3), dtype=torch.float32, pin_memory=True)
+            host_tile.copy_(raw)
+            dev_tile = torch.empty_like(raw)
+            torch.cuda.synchronize()
+            times = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                dev_tile.copy_(host_tile, non_blocking=True)
+                c2 = pipeline.cluster_points(dev_tile, EPS, MIN_POINTS, CHUNK)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            dev_tile.copy_(host_tile, non_blocking=True)
+            torch.cuda.synchronize()
+            t_copy = time.perf_counter() - t0
+            out["h2d_inclusive"] = {"ms_per_step": round(1e3 * min(times), 3), "Mpts_per_s": round(N / min(times) / 1e6, 1),
+                                    "h2d_ms": round(1e3 * t_copy, 3), "h2d_GBps": round(12 * N / t_copy / 1e9, 1),
+                                    "clusters": int(c2["nclusters"]),
+                                    "note": "pinned host float32 [N,3] -> device copy -> one step, best of 3; measured, "
+                                            "not the reported value (the input of `value` is resident in HBM)"}
+            del host_tile, dev_tile, c2
+        except Exception as e:
+            out["h2d_inclusive"] = {"error": f"{type(e).__name__}: {e}"}
 
         # stage D1-D3 on the clusters of the timed tile (host: per-cluster oriented boxes; SURVEY 8f "next"):
         # exact mode through the worker pool (one worker per usable core, shared-memory hand-off), with its split

@@ -62,7 +62,9 @@ names = {"ms_summary_k": "mean_summary", "ms_walk_k": "mean_walk", "ms_level2_k"
          "db_cells_k": "db_cells", "ms_sample_k": "mean_sample", "ms_prefix_k": "mean_prefix",
          "scan1_k<false>": "scan1", "scan1_k<true>": "scan1_popc", "db_prelabel_k": "db_prelabel",
          "sl_hist_k": "seg_hist", "sl_scatter_k": "seg_scatter", "sl_offsets_k": "seg_offsets"}
-traffic = {"points": int(points), "kind": kind, "frame": frame, "source": tag,
+sys.path.insert(0, here)
+from stamp import csrc_sha            # noqa: E402
+traffic = {"points": int(points), "kind": kind, "frame": frame, "source": tag, "csrc_sha": csrc_sha(),
            "unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, KiB->B)", "kernels": {}}
 with open(os.path.join(here, f"{tag}_pmc_traffic.csv"), "w") as f:
     f.write("kernel,launches,fetch_bytes_raw_per_launch,fetch_bytes_x2_per_launch,write_bytes_per_launch\n")

@@ -191,7 +191,7 @@ def test_tower_table_through_the_pool_is_the_serial_loop_and_may_run_beside_the_
             for key in ("center", "rotation", "extent"):
                 assert np.array_equal(np.asarray(x[key]), np.asarray(y[key])), key
             assert x["north_angle"] == y["north_angle"]
-            assert np.array_equal(x["points"], host[offs[x["label"]]:offs[x["label"] + 1]])
+            assert np.array_equal(y["points"], host[offs[x["label"]]:offs[x["label"] + 1]])
 
     same(want, got)
     # in flight beside the next tile's device work; two tables at once use two buffers

@@ -21,6 +21,14 @@ for _ in range(5):
     out = ops.voxel_downsample(xyz, voxel, chunk)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 5
+each = []
+for _ in range(4):
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    out = ops.voxel_downsample(xyz, voxel, chunk)
+    torch.cuda.synchronize()
+    each.append(round((time.perf_counter() - t1) * 1e3, 3))
+print("single calls (ms):", each, "reserved GB:", round(torch.cuda.memory_reserved() / 1e9, 2))
 print(f"{n} pts, voxel {voxel}, chunk {chunk}: {dt * 1e3:.3f} ms = {n / dt / 1e6:.0f} Mpts/s, {out[0].shape[0]} voxels")
 ops.set_profiling(True)
 for _ in range(3):
