@@ -205,11 +205,11 @@ __global__ __launch_bounds__(VP_THREADS) void vx_tilehist_k(const double* __rest
 struct VoxelBatch {
     uint32_t row0;        // first row (absolute, in the partitioned buffer) of the units this batch reads
     uint32_t rows;        // rows this batch sorts (0: nothing to do)
-    uint32_t span;        // rows to sweep: == rows, or the whole unit when the batch selects a part of it
+    uint32_t span;        // == rows; for the reserved slots of an oversize unit (before vx_split_k): the unit's rows
     uint16_t digit0;      // first level-1 digit of the batch
     uint16_t ndigits;     // level-1 digits covered (>= 1)
-    uint16_t sel_lo, sel_hi;   // sel_hi > sel_lo: only rows whose NEXT 8-bit digit lies in [sel_lo, sel_hi)
     uint32_t pad;
+    uint32_t from_b;      // 1: the batch's rows lie in the second row buffer (a part of an oversize unit, vx_split_k)
 };
 struct VoxelOversize { uint32_t slot, nsub; };             // a unit above VF_CAP rows and its reserved batch slots
 
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(VP_MAXBINS) void vx_binscan_k(VoxelPlan g, uint32_t
         auto emit = [&](uint32_t r0, uint32_t nrows, uint32_t d0, uint32_t nd) {
             VoxelBatch v;
             v.row0 = r0; v.rows = nrows; v.span = nrows; v.digit0 = (uint16_t)d0; v.ndigits = (uint16_t)nd;
-            v.sel_lo = 0; v.sel_hi = 0; v.pad = 0;
+            v.pad = 0; v.from_b = 0;
             out[nbt++] = v;
         };
         // a batch covers the digits [first, last] of its first and last NON-EMPTY unit (empty units in between
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(VP_MAXBINS) void vx_binscan_k(VoxelPlan g, uint32_t
                 // batch slots or the 16-bit position field run out: then one batch, sorted in global memory
                 const uint32_t nsub = 2 * ((rows + VF_CAP - 1) / VF_CAP) + 1;
                 const uint32_t left = nonempty - seen;                    // units still to come need <= 1 slot each
-                if (rows <= 65535u && g.rem > 0 && g.rem <= 32 && nbt + nsub + left <= (uint32_t)VP_MAXBINS) {
+                if (g.rem > 0 && g.rem <= 32 && nbt + nsub + left <= (uint32_t)VP_MAXBINS) {
                     const uint32_t o = atomicAdd(nover, 1u);
                     over[o].slot = (uint32_t)(c * VP_MAXBINS) + nbt;
                     over[o].nsub = nsub;
@@ -298,13 +298,21 @@ __global__ __launch_bounds__(VP_MAXBINS) void vx_binscan_k(VoxelPlan g, uint32_t
     }
 }
 
-// one workgroup per oversize unit: histogram of its next 8-bit digit, then parts of <= VF_CAP rows
-__global__ __launch_bounds__(1024) void vx_split_k(VoxelPlan g, const double* __restrict__ minb,
-                                                  const Row* __restrict__ rows, VoxelBatch* __restrict__ batches,
-                                                  const VoxelOversize* __restrict__ over,
-                                                  const uint32_t* __restrict__ nover) {
-    __shared__ uint32_t hist[256];
+// one workgroup per oversize unit (a tower core: thousands of rows in one level-1 cell): a SECOND partition, by the
+// unit's next 8-bit digit, into the second row buffer (stable: histogram, then ranked scatter tile by tile); the parts of
+// <= VF_CAP rows that come out of it are contiguous there and are finished like any other batch.  (Until round 4 every
+// part swept the whole unit twice and picked its rows: 12 sweeps of a 20 000-row unit that was cut into six.)
+constexpr int VS_THREADS = 1024, VS_WAVES = VS_THREADS / 64, VS_ROUNDS = 4, VS_TILE = VS_THREADS * VS_ROUNDS;
+__global__ __launch_bounds__(VS_THREADS) void vx_split_k(VoxelPlan g, const double* __restrict__ minb,
+                                                       const Row* __restrict__ rows, Row* __restrict__ rows_b,
+                                                       VoxelBatch* __restrict__ batches,
+                                                       const VoxelOversize* __restrict__ over,
+                                                       const uint32_t* __restrict__ nover) {
+    __shared__ uint32_t hist[256], base[256];
+    __shared__ uint32_t cnt[VS_WAVES][256];
+    __shared__ uint32_t okflag;
     const uint32_t total = *nover;
+    const int tid = threadIdx.x, w = wave_id(), l = lane_id();
     for (uint32_t o = blockIdx.x; o < total; o += gridDim.x) {
         const VoxelOversize ov = over[o];
         VoxelBatch* bt = batches + ov.slot;
@@ -313,39 +321,96 @@ __global__ __launch_bounds__(1024) void vx_split_k(VoxelPlan g, const double* __
         const double mb[3] = {minb[3 * c + 0], minb[3 * c + 1], minb[3 * c + 2]};
         const int sh2 = g.rem > 8 ? g.rem - 8 : 0;
         const uint64_t remmask = (1ull << g.rem) - 1;
-        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        for (uint32_t i0 = 0; i0 < R; i0 += 4 * 1024) {
-            Row q[4];
+        for (uint32_t i0 = 0; i0 < R; i0 += VS_TILE) {
+            Row q[VS_ROUNDS];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t i = i0 + k * 1024 + threadIdx.x;
+            for (int k = 0; k < VS_ROUNDS; ++k) {
+                const uint32_t i = i0 + k * VS_THREADS + tid;
                 q[k] = rows[s + (i < R ? i : 0)];
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (i0 + k * 1024 + threadIdx.x < R)
+            for (int k = 0; k < VS_ROUNDS; ++k)
+                if (i0 + k * VS_THREADS + tid < R)
                     atomicAdd(&hist[(uint32_t)((vx_key(g, mb, q[k]) & remmask) >> sh2) & 255u], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t k = 0, acc = 0, lo = 0;
+        if (tid == 0) {
+            uint32_t k = 0, acc = 0, first = 0, run = 0;
             bool ok = true;
             for (uint32_t d = 0; d < 256 && ok; ++d) {
                 const uint32_t h = hist[d];
                 if (h > (uint32_t)VF_CAP) { ok = false; break; }
                 if (acc + h > (uint32_t)VF_CAP) {
-                    bt[k].rows = acc; bt[k].sel_lo = (uint16_t)lo; bt[k].sel_hi = (uint16_t)d; ++k;
-                    lo = d;
+                    bt[k].row0 = s + first; bt[k].rows = acc; bt[k].span = acc; bt[k].from_b = 1u; ++k;
+                    first = run;
                     acc = 0;
                 }
                 acc += h;
+                run += h;
             }
             if (ok) {
-                if (acc) { bt[k].rows = acc; bt[k].sel_lo = (uint16_t)lo; bt[k].sel_hi = 256; ++k; }
+                if (acc) { bt[k].row0 = s + first; bt[k].rows = acc; bt[k].span = acc; bt[k].from_b = 1u; ++k; }
+                for (uint32_t j = k; j < ov.nsub; ++j) { bt[j].rows = 0; bt[j].span = 0; }
             } else {                                       // one voxel column alone exceeds the LDS capacity:
-                for (uint32_t j = 0; j < ov.nsub; ++j) { bt[j].rows = 0; bt[j].sel_lo = bt[j].sel_hi = 0; }
+                for (uint32_t j = 0; j < ov.nsub; ++j) { bt[j].rows = 0; bt[j].from_b = 0; }
                 bt[0].rows = R;                            // the whole unit as one batch, sorted in global memory
+            }
+            okflag = ok ? 1u : 0u;
+        }
+        __syncthreads();
+        if (okflag) {                                      // workgroup-uniform
+            // exclusive scan of the digit histogram -> where every digit's rows start in the second buffer
+            uint32_t hv = tid < 256 ? hist[tid] : 0u;
+            const uint32_t incl = wave_scan_incl(hv);
+            if (tid < 256 && l == 63) cnt[0][w] = incl;    // (cnt[0][0..3]: the four waves' totals, consumed below)
+            __syncthreads();
+            if (tid < 256) {
+                uint32_t b = incl - hv;
+                for (int w2 = 0; w2 < w; ++w2) b += cnt[0][w2];
+                base[tid] = s + b;
+            }
+            __syncthreads();
+            for (uint32_t t0 = 0; t0 < R; t0 += VS_TILE) {
+                for (int j = tid; j < VS_WAVES * 256; j += VS_THREADS) (&cnt[0][0])[j] = 0;
+                __syncthreads();
+                const uint32_t segb = t0 + w * (64 * VS_ROUNDS);     // wave w owns 256 consecutive rows of the tile
+                Row q[VS_ROUNDS];
+                uint32_t dig[VS_ROUNDS], rank[VS_ROUNDS];
+#pragma unroll
+                for (int r = 0; r < VS_ROUNDS; ++r) {
+                    const uint32_t i = segb + r * 64 + l;
+                    q[r] = rows[s + (i < R ? i : 0)];
+                }
+#pragma unroll
+                for (int r = 0; r < VS_ROUNDS; ++r) {
+                    const bool valid = segb + r * 64 + l < R;
+                    dig[r] = (uint32_t)((vx_key(g, mb, q[r]) & remmask) >> sh2) & 255u;
+                    uint32_t npeer;
+                    const uint32_t rk = wave_match<8>(dig[r], valid, npeer);
+                    const uint32_t prior = cnt[w][dig[r]];
+                    __builtin_amdgcn_wave_barrier();
+                    if (valid && rk == 0) cnt[w][dig[r]] = prior + npeer;
+                    __builtin_amdgcn_wave_barrier();
+                    rank[r] = prior + rk;
+                }
+                __syncthreads();
+                if (tid < 256) {                           // per digit: waves in order
+                    uint32_t run = base[tid];
+#pragma unroll
+                    for (int w2 = 0; w2 < VS_WAVES; ++w2) {
+                        const uint32_t cc = cnt[w2][tid];
+                        cnt[w2][tid] = run;
+                        run += cc;
+                    }
+                    base[tid] = run;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < VS_ROUNDS; ++r)
+                    if (segb + r * 64 + l < R) rows_b[cnt[w][dig[r]] + rank[r]] = q[r];
+                __syncthreads();
             }
         }
         __syncthreads();
@@ -528,7 +593,7 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
         const VoxelBatch bt = batches[c * VP_MAXBINS + (t - batch_prefix[c])];
         const bool first_of_chunk = t == batch_prefix[c];
         const uint32_t s = bt.row0, R = bt.rows;
-        const bool selecting = bt.sel_hi > bt.sel_lo;
+        const Row* __restrict__ src = bt.from_b ? bufB : bufA;      // where this batch's rows are
         const uint64_t d0 = bt.digit0;
         const double mb[3] = {minb[3 * c + 0], minb[3 * c + 1], minb[3 * c + 2]};
         int dbits = 0;
@@ -552,7 +617,7 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
         // A batch with a voxel of more than VQ_MAXRUN rows takes the stable sort below instead.
         bool grouped = false, skip_early = false;
         uint32_t gkey[VP_ROUNDS], ghs[VP_ROUNDS];           // grouping path: relative key; slot | arrival ticket << 16
-        if (R != 0 && !selecting && R <= (uint32_t)VF_CAP && sortbits <= 31) {
+        if (R != 0 && R <= (uint32_t)VF_CAP && sortbits <= 31) {
             for (uint32_t j = tid; j < VQ_SLOTS; j += VF_THREADS) sh.q.hset[j] = 0xFFFFFFFFu;
             for (uint32_t j = tid; j < VQ_SLOTS / 4; j += VF_THREADS) sh.q.hcnt[j] = 0u;
             if (tid == 0) sh.overflow = 0u;
@@ -566,7 +631,7 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
 #pragma unroll
                 for (int r = 0; r < VP_ROUNDS / 2; ++r) {
                     const uint32_t i = (h * (VP_ROUNDS / 2) + r) * VF_THREADS + tid;
-                    q[r] = bufA[s + (i < R ? i : 0)];
+                    q[r] = src[s + (i < R ? i : 0)];
                 }
 #pragma unroll
                 for (int r = 0; r < VP_ROUNDS / 2; ++r) {
@@ -708,7 +773,7 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
                 __syncthreads();
             }
             announced = early || skip_early;
-            if (!selecting && skip_early) {
+            if (skip_early) {
                 // the grouping path above has computed the keys and announced the count, then stood down (rows share
                 // voxels, or a voxel holds more rows than it takes): its keys are still in registers
 #pragma unroll
@@ -716,7 +781,7 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
                     const uint32_t i = r * VF_THREADS + tid;
                     if (i < R) { sh.key[0][i] = gkey[r]; sh.perm[0][i] = (uint16_t)i; }
                 }
-            } else if (!selecting) {
+            } else {
                 uint32_t kreg[VP_ROUNDS];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {               // four rows per thread in flight
@@ -724,7 +789,7 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
 #pragma unroll
                     for (int r = 0; r < VP_ROUNDS / 2; ++r) {
                         const uint32_t i = (h * (VP_ROUNDS / 2) + r) * VF_THREADS + tid;
-                        q[r] = bufA[s + (i < R ? i : 0)];
+                        q[r] = src[s + (i < R ? i : 0)];
                     }
 #pragma unroll
                     for (int r = 0; r < VP_ROUNDS / 2; ++r) {
@@ -740,55 +805,6 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
                 for (int r = 0; r < VP_ROUNDS; ++r) {
                     const uint32_t i = r * VF_THREADS + tid;
                     if (i < R) { sh.key[0][i] = kreg[r]; sh.perm[0][i] = (uint16_t)i; }
-                }
-            } else {
-                // part of an oversize unit: sweep the whole unit (it sits in L2) and keep, in file order, the rows
-                // whose next digit lies in [sel_lo, sel_hi)
-                const int sh2 = g.rem > 8 ? g.rem - 8 : 0;
-                uint32_t filled = 0;
-                constexpr int SW = 4;                      // rows per thread in flight
-                // the low `rem` key bits of SW rows per thread
-                auto sweep_keys = [&](uint32_t t0, uint32_t (&krs)[SW]) {
-                    Row q[SW];
-#pragma unroll
-                    for (int k = 0; k < SW; ++k) {
-                        const uint32_t i = t0 + k * VF_THREADS + tid;
-                        q[k] = bufA[s + (i < bt.span ? i : 0)];
-                    }
-#pragma unroll
-                    for (int k = 0; k < SW; ++k) krs[k] = (uint32_t)(vx_key(g, mb, q[k]) & remmask);
-                };
-                if (early) {                               // first sweep: distinct keys only
-                    for (uint32_t t0 = 0; t0 < bt.span; t0 += SW * VF_THREADS) {
-                        uint32_t krs[SW];
-                        sweep_keys(t0, krs);
-#pragma unroll
-                        for (int k = 0; k < SW; ++k) {
-                            const uint32_t i = t0 + k * VF_THREADS + tid;
-                            const uint32_t kr = krs[k];
-                            const uint32_t d2 = (kr >> sh2) & 255u;
-                            if (i < bt.span && d2 >= bt.sel_lo && d2 < bt.sel_hi) insert(kr);
-                        }
-                    }
-                    count_and_announce();
-                }
-                for (uint32_t t0 = 0; t0 < bt.span; t0 += SW * VF_THREADS) {
-                    uint32_t krs[SW];
-                    sweep_keys(t0, krs);
-#pragma unroll
-                    for (int k = 0; k < SW; ++k) {
-                        const uint32_t i = t0 + k * VF_THREADS + tid;
-                        if (t0 + k * VF_THREADS >= bt.span) break;                  // workgroup-uniform
-                        const uint32_t kr = krs[k];
-                        const uint32_t d2 = (kr >> sh2) & 255u;
-                        const bool sel = i < bt.span && d2 >= bt.sel_lo && d2 < bt.sel_hi;
-                        const uint64_t m = __ballot(sel);
-                        uint32_t tot;
-                        const uint32_t wbase = vf_block_scan(l == 0 ? (uint32_t)__popcll(m) : 0u, sh.wsum, tot);
-                        const uint32_t at = filled + __shfl(wbase, 0, 64) + (uint32_t)__popcll(m & lanemask_lt());
-                        if (sel) { sh.key[0][at] = kr; sh.perm[0][at] = (uint16_t)i; }
-                        filled += tot;
-                    }
                 }
             }
             __syncthreads();
@@ -992,22 +1008,35 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
             // The first rows of all (up to eight) voxels of a thread are requested together; further rows of a voxel
             // follow one after the other (file order), which few voxels need.
 #pragma unroll
-            for (int r = 0; r < VP_ROUNDS; ++r) {
-                if (ghs[r] != 0xFFFFFFFFu && (ghs[r] >> 16) == 0u) {
-                    const uint32_t slot = ghs[r] & 0xFFFFu;
-                    const uint32_t a0 = sh.q.sstart[slot];
-                    const uint32_t cn = (sh.q.hcnt[slot >> 2] >> (8 * (slot & 3u))) & 255u;
-                    const uint32_t p0 = sh.q.pos[a0];
-                    double ax = 0.0, ay = 0.0, az = 0.0;
-                    for (uint32_t a = 0; a < cn; ++a) {
-                        const Row q = bufA[s + sh.q.pos[a0 + a]];
-                        ax += q.x; ay += q.y; az += q.z;
+            for (int h = 0; h < 2; ++h) {                   // four voxels' first rows in flight per thread
+                constexpr int HV = VP_ROUNDS / 2;
+                uint32_t a0[HV], cn[HV], p0[HV];
+                Row q0[HV];
+#pragma unroll
+                for (int j = 0; j < HV; ++j) {
+                    const int r = h * HV + j;
+                    const bool owner = ghs[r] != 0xFFFFFFFFu && (ghs[r] >> 16) == 0u;
+                    const uint32_t slot = owner ? (ghs[r] & 0xFFFFu) : 0u;
+                    a0[j] = sh.q.sstart[slot];
+                    cn[j] = owner ? (sh.q.hcnt[slot >> 2] >> (8 * (slot & 3u))) & 255u : 0u;
+                    p0[j] = owner ? sh.q.pos[a0[j]] : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < HV; ++j) q0[j] = src[s + p0[j]];
+#pragma unroll
+                for (int j = 0; j < HV; ++j) {
+                    if (cn[j] != 0u) {
+                        double ax = 0.0 + q0[j].x, ay = 0.0 + q0[j].y, az = 0.0 + q0[j].z;   // AddPoint starts from +0.0
+                        for (uint32_t a = 1; a < cn[j]; ++a) {
+                            const Row q = src[s + sh.q.pos[a0[j] + a]];
+                            ax += q.x; ay += q.y; az += q.z;
+                        }
+                        const uint32_t v = sh.q.headpre[p0[j] >> 6] +
+                                           (uint32_t)__popcll(sh.q.headbits[p0[j] >> 6] & ((1ull << (p0[j] & 63u)) - 1ull));
+                        const uint64_t sk = gkey[h * HV + j];
+                        const uint64_t key = ((d0 + (sk >> g.rem)) << g.rem) | (sk & remmask);
+                        vf_emit(g, key, ax, ay, az, cn[j], vbase + v, out_idx, out_mean, out_count);
                     }
-                    const uint32_t v = sh.q.headpre[p0 >> 6] +
-                                       (uint32_t)__popcll(sh.q.headbits[p0 >> 6] & ((1ull << (p0 & 63u)) - 1ull));
-                    const uint64_t sk = gkey[r];
-                    const uint64_t key = ((d0 + (sk >> g.rem)) << g.rem) | (sk & remmask);
-                    vf_emit(g, key, ax, ay, az, cn, vbase + v, out_idx, out_mean, out_count);
                 }
             }
         } else if (in_lds) {
@@ -1015,7 +1044,7 @@ __global__ __launch_bounds__(VF_THREADS, (2 * VF_THREADS) / 256) void vx_finish_
                 const uint32_t a0 = vst[v], a1 = v + 1 < nvox ? vst[v + 1] : R;
                 double ax = 0.0, ay = 0.0, az = 0.0;
                 for (uint32_t i = a0; i < a1; ++i) {
-                    const Row q = bufA[s + sperm[i]];
+                    const Row q = src[s + sperm[i]];
                     ax += q.x; ay += q.y; az += q.z;
                 }
                 const uint64_t sk = srt[a0];
@@ -1160,8 +1189,8 @@ extern "C" int pch_voxel_downsample_f64(const double* xyz, int64_t n, double vox
     {   // units above the LDS capacity (dense columns): split by their next digit, one workgroup each
         int64_t sg = nchunks * g.nb;
         if (sg > 512) sg = 512;
-        PCH_LAUNCH("voxel_split", vx_split_k, dim3((unsigned)sg), dim3(1024), 0, s, g, (const double*)w.minb,
-                   (const Row*)w.bufA, w.batches, (const VoxelOversize*)w.over, (const uint32_t*)w.nover);
+        PCH_LAUNCH("voxel_split", vx_split_k, dim3((unsigned)sg), dim3(VS_THREADS), 0, s, g, (const double*)w.minb,
+                   (const Row*)w.bufA, w.bufB, w.batches, (const VoxelOversize*)w.over, (const uint32_t*)w.nover);
     }
     // persistent finisher: two 512-thread workgroups per CU draw the batches in order
     int dev = 0, cus = 256;
