@@ -21,6 +21,16 @@ int pch_obbhost_version(void);
 int pch_obbhost_search_f64(const double* verts, int64_t nv, const double* angles, int64_t nc, int32_t* out_best,
                            double* out_volumes);
 
+/* What qhull is shown of one cluster: the rows that are NOT strictly inside the tetrahedron qhull starts from (such
+ * rows are inert in qhull's run; about a third of a tower cluster), as float64, in input order.  The tetrahedron is
+ * predicted from qhull's own rule (libqhull_r 2019.1: qh_maxmin + qh_maxsimplex); where that choice could hinge on
+ * rounding or on qhull's 'search all points' rule the call stands down and copies every row.
+ * pts [n,3] float32 / float64; out [n,3] float64 capacity; *out_rows: rows written.
+ * Returns 1 = reduced, 0 = all rows copied, -1 = bad argument.  See pointcloudhookup_amd/obb.py for the argument why
+ * the hull, its facet order and hence the box search are unchanged, and how that is checked. */
+int pch_obbhost_reduce_f32(const float* pts, int64_t n, double* out, int64_t* out_rows);
+int pch_obbhost_reduce_f64(const double* pts, int64_t n, double* out, int64_t* out_rows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,4 +15,14 @@ extern "C" int pch_obbhost_search_f64(const double* verts, int64_t nv, const dou
     return 0;
 }
 
-extern "C" int pch_obbhost_version(void) { return 1; }
+extern "C" int pch_obbhost_reduce_f32(const float* pts, int64_t n, double* out, int64_t* out_rows) {
+    if (n < 0 || !out_rows || (n > 0 && (!pts || !out))) return -1;
+    return pch::obbhost::reduce_for_qhull(pts, n, out, out_rows) ? 1 : 0;
+}
+
+extern "C" int pch_obbhost_reduce_f64(const double* pts, int64_t n, double* out, int64_t* out_rows) {
+    if (n < 0 || !out_rows || (n > 0 && (!pts || !out))) return -1;
+    return pch::obbhost::reduce_for_qhull(pts, n, out, out_rows) ? 1 : 0;
+}
+
+extern "C" int pch_obbhost_version(void) { return 2; }

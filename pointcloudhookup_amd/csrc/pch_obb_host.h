@@ -225,5 +225,94 @@ inline int32_t search_hull(const double* v, int64_t nv, const double* angles, in
     return best;
 }
 
+// ---- what qhull is shown (pointcloudhookup_amd/obb.py, "what qhull is shown"): the points of a cluster that are NOT
+// strictly inside the tetrahedron qhull starts from.  Prediction of that tetrahedron after libqhull_r 2019.1
+// (qh_maxmin + qh_maxsimplex): candidates = first minimum and maximum point of every coordinate; the x-extremes, then
+// the candidate with the largest |2x2 determinant| of the (unit-box scaled) x,y differences, then the largest |3x3
+// determinant|.  Stands down (returns false: show qhull everything) when the choice could hinge on rounding or on
+// qhull's 'search all points' rule.  pts: n rows of three floats or doubles; out: room for n rows of three doubles.
+template <typename T>
+inline bool reduce_for_qhull(const T* pts, int64_t n, double* out, int64_t* out_rows) {
+    auto all = [&]() {
+        for (int64_t i = 0; i < 3 * n; ++i) out[i] = (double)pts[i];
+        *out_rows = n;
+        return false;
+    };
+    if (n < 64) return all();
+    int64_t mp[6];
+    double lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) {
+        int64_t imin = 0, imax = 0;
+        double vmin = (double)pts[k], vmax = vmin;
+        for (int64_t i = 1; i < n; ++i) {
+            const double v = (double)pts[3 * i + k];
+            if (v < vmin) { vmin = v; imin = i; }          // strict: the first occurrence stays
+            if (v > vmax) { vmax = v; imax = i; }
+        }
+        if (!(vmax > vmin) || !(fabs(vmax) < INFINITY) || !(fabs(vmin) < INFINITY)) return all();
+        mp[2 * k] = imin; mp[2 * k + 1] = imax; lo[k] = vmin; hi[k] = vmax;
+    }
+    double q[6][3];
+    for (int i = 0; i < 6; ++i)
+        for (int k = 0; k < 3; ++k) q[i][k] = ((double)pts[3 * mp[i] + k] - lo[k]) / (hi[k] - lo[k]);
+    int sel[4] = {0, 1, -1, -1};                           // positions in mp[]: the x-extremes first
+    if (mp[0] == mp[1]) return all();
+    double prev = q[1][0] - q[0][0];
+    for (int k = 2; k <= 3; ++k) {
+        double best = -1.0, second = -1.0;
+        int ibest = -1;
+        for (int i = 0; i < 6; ++i) {
+            bool used = false;
+            for (int j = 0; j < k; ++j) used |= mp[sel[j]] == mp[i];
+            if (used) continue;
+            double d;
+            if (k == 2) {
+                const double a0 = q[sel[0]][0] - q[i][0], a1 = q[sel[0]][1] - q[i][1];
+                const double b0 = q[sel[1]][0] - q[i][0], b1 = q[sel[1]][1] - q[i][1];
+                d = fabs(a0 * b1 - a1 * b0);
+            } else {
+                double r[3][3];
+                for (int j = 0; j < 3; ++j) for (int c = 0; c < 3; ++c) r[j][c] = q[sel[j]][c] - q[i][c];
+                d = fabs(r[0][0] * (r[1][1] * r[2][2] - r[1][2] * r[2][1]) - r[0][1] * (r[1][0] * r[2][2] - r[1][2] * r[2][0]) +
+                         r[0][2] * (r[1][0] * r[2][1] - r[1][1] * r[2][0]));
+            }
+            if (ibest >= 0 && mp[i] == mp[ibest]) continue;               // the same point twice among the candidates
+            if (d > best) { second = best; best = d; ibest = i; }
+            else if (d > second) second = d;
+        }
+        if (ibest < 0) return all();
+        if (second > best * (1.0 - 1e-6)) return all();    // qhull's own rounding would decide
+        if (!(best > 0.05 * prev)) return all();           // too close to qhull's 'search all points' regime
+        prev = best;
+        sel[k] = ibest;
+    }
+    // barycentric coordinates with respect to the tetrahedron (in the points' own frame)
+    double t0[3], m[3][3];
+    for (int c = 0; c < 3; ++c) t0[c] = (double)pts[3 * mp[sel[0]] + c];
+    for (int j = 0; j < 3; ++j)
+        for (int c = 0; c < 3; ++c) m[c][j] = (double)pts[3 * mp[sel[j + 1]] + c] - t0[c];   // columns = edges
+    const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                       m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+    if (!(fabs(det) > 0.0) || !(fabs(det) < INFINITY)) return all();
+    double inv[3][3];
+    inv[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) / det; inv[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) / det;
+    inv[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) / det; inv[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) / det;
+    inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det; inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
+    inv[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) / det; inv[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det;
+    inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
+    int64_t kept = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double x = (double)pts[3 * i], y = (double)pts[3 * i + 1], z = (double)pts[3 * i + 2];
+        const double dx = x - t0[0], dy = y - t0[1], dz = z - t0[2];
+        const double b0 = inv[0][0] * dx + inv[0][1] * dy + inv[0][2] * dz;
+        const double b1 = inv[1][0] * dx + inv[1][1] * dy + inv[1][2] * dz;
+        const double b2 = inv[2][0] * dx + inv[2][1] * dy + inv[2][2] * dz;
+        const bool inside = b0 > 1e-6 && b1 > 1e-6 && b2 > 1e-6 && (b0 + b1 + b2) < 1.0 - 1e-6;
+        if (!inside) { out[3 * kept] = x; out[3 * kept + 1] = y; out[3 * kept + 2] = z; ++kept; }
+    }
+    *out_rows = kept;
+    return kept < n;
+}
+
 }  // namespace obbhost
 }  // namespace pch

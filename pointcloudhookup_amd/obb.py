@@ -29,9 +29,134 @@ _TOL = np.finfo(np.float64).resolution * 100.0
 _EXTENT_ORDERS = ("unsorted", "trimesh_sorted")
 
 
+# ---- what qhull is shown ---------------------------------------------------------------------------------
+# qhull's cost is linear in the number of points it is SHOWN (~0.15 us per point: every point is partitioned against
+# the facets of the initial simplex before anything else happens), and a third of a tower cluster lies strictly inside
+# that very simplex.  Such a point is inert in qhull's run: it is below every initial facet, so it never enters an outside
+# set, never becomes a (temporary) vertex, and leaves no trace in the facet list - the run on the remaining points is the
+# same run, facet for facet, in the same order (which is what the candidate list of the box search depends on).
+# The initial simplex is predicted from qhull's own rule (libqhull_r 2019.1, qh_maxmin + qh_maxsimplex, as bundled with
+# scipy): the first minimum and maximum point of every coordinate are the candidates; the x-extremes come first, then the
+# candidate with the largest |2x2 determinant| of the x,y differences, then the one with the largest |3x3 determinant|
+# (the unit-box scaling of 'QbB' multiplies all determinants of a step by the same factor).  The prediction stands down
+# - qhull then sees every point - whenever qhull's choice could hinge on rounding or on its 'search all points' rule:
+# candidates whose determinants are within 1e-6 of the best, a determinant below 5 % of what the extents allow (qhull
+# searches from 0.1 % down), fewer than 64 points, a zero extent.  Points count as inside only when all four barycentric
+# coordinates exceed 1e-6 (qhull's own tolerances are ~1e-13 of the unit box).
+# Checked against qhull itself: hull vertices, triangles and candidate directions of the full and the reduced input are
+# identical on 48 400 random clusters of seven shapes (tools/prefilter_check.py; a deliberately wrong tetrahedron shows
+# up there as mismatches), on every cluster of the test suite, and once per process on four synthetic towers
+# (_prefilter_ok: a qhull build that chooses differently switches the reduction off).  PCH_OBB_PREFILTER=0 disables it.
+_PREFILTER = None
+
+
+def predicted_simplex(p):
+    """indices of the four points qhull starts from, or None where the prediction stands down"""
+    n = len(p)
+    if n < 64:
+        return None
+    lo, hi = p.min(axis=0), p.max(axis=0)
+    w = hi - lo
+    if not (w > 0).all() or not np.isfinite(w).all():
+        return None
+    mp = []
+    for k in range(3):                                   # first occurrence, like qhull's strict comparisons
+        mp += [int(p[:, k].argmin()), int(p[:, k].argmax())]
+    q = (p[mp] - lo) / w
+    s = [mp[0], mp[1]]                                    # the extremes of x (set order: min first)
+    if s[0] == s[1]:
+        return None
+    prev = float(q[1, 0] - q[0, 0])
+    for k in (2, 3):
+        cands = []
+        for i in range(6):
+            if mp[i] in s:
+                continue
+            rows = np.array([q[mp.index(sj)][:k] - q[i][:k] for sj in s[:k]])
+            cands.append((abs(float(np.linalg.det(rows))), mp[i]))
+        if not cands:
+            return None
+        cands.sort(key=lambda t: -t[0])
+        best = cands[0]
+        if any(c != best[1] and d > best[0] * (1.0 - 1e-6) for d, c in cands[1:]):
+            return None                                   # qhull's own rounding would decide
+        if not best[0] > 0.05 * prev:
+            return None                                   # too close to qhull's 'search all points' regime
+        prev = best[0]
+        s.append(best[1])
+    return s
+
+
+def qhull_input(points):
+    """float64 [m,3]: what qhull is shown of ``points`` ([n,3] float32 or float64) - all of them, or (natively,
+    pch_obbhost_reduce_*) all but the rows strictly inside qhull's initial simplex"""
+    global _PREFILTER
+    if _PREFILTER is None:
+        import os
+        _PREFILTER = False                                # (the self-check below runs the unreduced path)
+        _PREFILTER = (os.environ.get("PCH_OBB_PREFILTER", "1") != "0" and _hostlib() is not None
+                      and _prefilter_ok())
+    a = np.ascontiguousarray(points)
+    if not _PREFILTER or a.ndim != 2 or a.shape[1] != 3 or a.dtype not in (np.float32, np.float64) or len(a) < 64:
+        return np.asarray(points, dtype=np.float64)
+    return _reduced_native(a)
+
+
+def _reduced_native(a):
+    import ctypes as C
+    lib = _hostlib()
+    out = np.empty((len(a), 3), dtype=np.float64)
+    rows = C.c_int64(0)
+    fn = lib.pch_obbhost_reduce_f32 if a.dtype == np.float32 else lib.pch_obbhost_reduce_f64
+    rc = fn(a.ctypes.data, len(a), out.ctypes.data, C.addressof(rows))
+    if rc < 0:
+        return np.asarray(a, dtype=np.float64)
+    return out[: rows.value]
+
+
+def _reduced(p):
+    s = predicted_simplex(p)
+    if s is None:
+        return p, None
+    T = p[s]
+    try:
+        A = np.linalg.inv((T[1:] - T[0]).T)
+    except np.linalg.LinAlgError:
+        return p, None
+    b = (p - T[0]) @ A.T
+    inside = (b > 1e-6).all(axis=1) & (b.sum(axis=1) < 1.0 - 1e-6)
+    if not inside.any():
+        return p, None
+    keep = np.flatnonzero(~inside)
+    return p[keep], keep
+
+
+def _prefilter_ok():
+    """once per process: does THIS qhull build start from the predicted simplex?  Four synthetic towers, full against
+    reduced input (the native reduction, as used): hull vertices, triangles in qhull's order and facet equations must
+    be identical; any difference (or exception) switches the reduction off."""
+    try:
+        rng = np.random.default_rng(20261004)
+        for i in range(4):
+            c = (rng.normal(size=(6000, 3)) * [2.5 + i, 2.5, 9.0] + [30.0 * i, -7.0, 22.0]).astype(np.float32)
+            if i == 3:
+                c = (c.astype(np.float64) @ np.linalg.qr(rng.normal(size=(3, 3)))[0]).astype(np.float32)
+            full = np.asarray(c, dtype=np.float64)
+            sub = _reduced_native(np.ascontiguousarray(c))
+            if len(sub) == len(full):
+                continue
+            a = ConvexHull(full, qhull_options="QbB Pp Qt")
+            b = ConvexHull(sub, qhull_options="QbB Pp Qt")
+            if not (np.array_equal(full[a.simplices], sub[b.simplices]) and np.array_equal(a.equations, b.equations)):
+                return False
+        return True
+    except Exception:
+        return False
+
+
 def hull_vertices_normals(points):
     """qhull ('QbB Pp Qt') hull: vertices in ascending input order + unit triangle normals."""
-    p = np.asarray(points, dtype=np.float64)
+    p = qhull_input(points)
     hull = ConvexHull(p, qhull_options="QbB Pp Qt")
     keep = np.sort(hull.vertices)
     remap = np.zeros(len(p), dtype=np.int64)
@@ -159,7 +284,7 @@ def bounding_box_oriented(points, extent_order="unsorted"):
 
 def _hull_triangles(points):
     """(hull vertices [nv,3] in ascending input order, triangles [nt,3] int32 into them, qhull's order)."""
-    p = np.asarray(points, dtype=np.float64)
+    p = qhull_input(points)
     hull = ConvexHull(p, qhull_options="QbB Pp Qt")
     ids = np.sort(hull.vertices)
     remap = np.empty(len(p), dtype=np.int32)
@@ -194,6 +319,9 @@ def _hostlib():
             lib = C.CDLL(path)
             lib.pch_obbhost_search_f64.restype = C.c_int
             lib.pch_obbhost_search_f64.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+            for fn in (lib.pch_obbhost_reduce_f32, lib.pch_obbhost_reduce_f64):
+                fn.restype = C.c_int
+                fn.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
             _HOSTLIB = lib
         except OSError:
             _HOSTLIB = False

@@ -353,32 +353,50 @@ def _exchange(header, payloads, caps, comm_dev, group, extra=()):
     return unpack(out, caps), [int(v) for v in need], out[:, len(payloads):nh]
 
 
-def strip_representatives(points, rows, labels, core, x_from, x_to, eps):
-    """One (global row, local cluster) pair per LATTICE cell that holds a core point with x in [x_from, x_to).
-    The lattice is the same on every rank: cell = floor(double(coordinate) / side) per axis, side = eps/sqrt(3)
-    (1 - 2^-16), anchored at the origin of the (shared, centred) frame - so two tiles that both hold the points of
-    such a strip, with the same core flags, name the SAME rows: the smallest global core row of every cell.  Two
-    points of one cell are closer than eps, so the core points of a cell are one cluster in either tile.
+def strip_representatives(points, rows, labels, core, strips, eps):
+    """For every strip (x_from, x_to) of ``strips``: one (global row, local cluster) pair per LATTICE cell that holds a
+    core point with x in [x_from, x_to).  The lattice is the same on every rank: cell = floor(double(coordinate) / side)
+    per axis, side = eps/sqrt(3) (1 - 2^-16), anchored at the origin of the (shared, centred) frame - so two tiles that
+    both hold the points of such a strip, with the same core flags, name the SAME rows: the smallest global core row of
+    every cell.  Two points of one cell are closer than eps, so the core points of a cell are one cluster in either
+    tile.  The strips must not overlap (a tile is at least one halo wide).
     points [n,3] float32, rows [n] int64 ascending, labels [n] int64, core [n] bool (same device).
-    Returns int64 [m,2] sorted by row."""
+    Returns a list of int64 [m,2] tensors sorted by row, one per strip (all strips in ONE pass: three host reads)."""
+    none = torch.zeros((0, 2), dtype=torch.int64, device=points.device)
+    if not strips:
+        return []
+    if len(strips) > 2:
+        raise ValueError("strip_representatives: at most two strips per call")
     x = points[:, 0]
-    pick = core & (labels >= 0) & (x >= float(x_from)) & (x < float(x_to))
-    idx = torch.nonzero(pick).squeeze(1)
+    sid = torch.full((points.shape[0],), -1, dtype=torch.int64, device=points.device)
+    for k, (a, b) in enumerate(strips):
+        sid = torch.where((x >= float(a)) & (x < float(b)), torch.full_like(sid, k), sid)
+    pick = core & (labels >= 0) & (sid >= 0)
+    idx = torch.nonzero(pick).squeeze(1)                                  # host read 1
     if idx.numel() == 0:
-        return torch.zeros((0, 2), dtype=torch.int64, device=points.device)
+        return [none for _ in strips]
     side = float(eps) / 3 ** 0.5 * (1.0 - 2.0 ** -16)
+    # 21 bits per axis: +-2^20 cells = +-4.8e6 m at eps = 8 m (the centred frame of an EPSG-scale cloud lies up to
+    # ~2.5e6 m from its origin: the float32 sequential "centroid" is that far off, utils/tower_extraction.py:63)
     c = torch.floor(points.index_select(0, idx).to(torch.float64) / side).to(torch.int64) + (1 << 20)
-    if int(c.min()) < 0 or int(c.max()) >= (1 << 21):
+    if bool(((c < 0) | (c >= (1 << 21))).any()):                          # host read 2
         raise ValueError("strip_representatives: coordinates beyond 2^20 lattice cells from the origin")
-    key = (c[:, 0] << 42) | (c[:, 1] << 21) | c[:, 2]
+    sk = sid.index_select(0, idx)
+    key = (sk << 63) | (c[:, 0] << 42) | (c[:, 1] << 21) | c[:, 2]
     r = rows.index_select(0, idx)
-    _, inv = torch.unique(key, return_inverse=True)
-    ncell = int(inv.max()) + 1
-    rep = torch.full((ncell,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=points.device)
+    uniq, inv = torch.unique(key, return_inverse=True)                    # host read 3 (its output size)
+    rep = torch.full((uniq.numel(),), torch.iinfo(torch.int64).max, dtype=torch.int64, device=points.device)
     rep.scatter_reduce_(0, inv, r, reduce="amin")
-    first = r == rep.index_select(0, inv)               # the row that represents its cell (rows are distinct)
-    out = torch.stack([r[first], labels.index_select(0, idx)[first]], dim=1)
-    return out[torch.argsort(out[:, 0])]
+    # the representative of cell u is the row rep[u]; its label: rows ascend, so look the row up again
+    at = torch.searchsorted(rows, rep)
+    lab = labels.index_select(0, at)
+    strip_of = (uniq >> 63) & 1
+    out = []
+    for k in range(len(strips)):
+        m = strip_of == k
+        pairs = torch.stack([rep[m], lab[m]], dim=1)
+        out.append(pairs[torch.argsort(pairs[:, 0])] if pairs.shape[0] else none)
+    return out
 
 
 def union_links(total, links, minrow):
@@ -503,10 +521,15 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
     # eps of e, and such a point has its exact core flag in BOTH tiles.  So both tiles publish (global row, local
     # cluster) for the core points with x in [e - eps, e + eps) - one per lattice cell, the same rows on either side.
     none = torch.zeros((0, 2), dtype=torch.int64, device=wdev)
-    lower = none if rank == 0 else strip_representatives(pts_t, rows_d, lab_d, core_d, float(x_lo) - float(eps),
-                                                          float(x_lo) + float(eps), eps)
-    upper = none if rank == world - 1 else strip_representatives(pts_t, rows_d, lab_d, core_d,
-                                                                  float(x_hi) - float(eps), float(x_hi) + float(eps), eps)
+    strips, which = [], []
+    if rank > 0:
+        strips.append((float(x_lo) - float(eps), float(x_lo) + float(eps)))
+        which.append("lower")
+    if rank < world - 1:
+        strips.append((float(x_hi) - float(eps), float(x_hi) + float(eps)))
+        which.append("upper")
+    reps = dict(zip(which, strip_representatives(pts_t, rows_d, lab_d, core_d, strips, eps)))
+    lower, upper = reps.get("lower", none), reps.get("upper", none)
     _mark(timings, "pairs_built")
     got, _, words = _exchange([k, 2 * int(lower.shape[0]), 2 * int(upper.shape[0])],
                               [minrow, lower.reshape(-1), upper.reshape(-1)],

@@ -789,3 +789,75 @@ def test_obb_pool_jobs_in_flight_shared_buffers_and_a_dead_worker():
     for (a, ea), (b, eb) in zip(want, again):
         assert eb is None and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert obb.usable_cpus() >= 1 and 1 <= obb.default_workers() <= max(obb.POOL_CAP, 1)
+
+
+def test_qhull_is_shown_fewer_points_and_runs_the_same_run():
+    """Rows strictly inside qhull's initial simplex are inert in its run; obb.qhull_input leaves them out (natively,
+    pch_obbhost_reduce_*).  tools/prefilter_check.py compares hull vertices and candidate directions with the reduction
+    off and on, bit for bit, on random clusters of seven shapes (48 400 clean trials when this was written); here 200 of
+    them, the python statement of qhull's rule against the native one on what they decide, and the switches."""
+    from pointcloudhookup_amd import obb
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prefilter_check.py"), "7", "200"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-800:] + r.stderr[-800:]
+    rng = np.random.default_rng(3)
+    tower = (rng.normal(size=(20000, 3)) * [2.5, 2.5, 9]).astype(np.float32)
+    shown = obb.qhull_input(tower)
+    assert obb._PREFILTER is True and shown.dtype == np.float64 and 0.5 * len(tower) < len(shown) < len(tower)
+    s = obb.predicted_simplex(tower.astype(np.float64))            # the python statement of the same rule
+    T = tower[s].astype(np.float64)
+    b = (tower.astype(np.float64) - T[0]) @ np.linalg.inv((T[1:] - T[0]).T).T
+    inside = (b > 1e-6).all(axis=1) & (b.sum(axis=1) < 1 - 1e-6)
+    assert abs(int((~inside).sum()) - len(shown)) <= 2             # (rows within rounding of the 1e-6 margin may differ)
+    # stands down: few points, a zero extent, candidates that tie
+    assert len(obb.qhull_input(tower[:50])) == 50
+    flat = tower.copy(); flat[:, 1] = 3.0
+    assert len(obb.qhull_input(flat)) == len(flat)
+    cube = np.array([[x, y, z] for x in (0.0, 4.0) for y in (0.0, 6.0) for z in (0.0, 20.0)] * 10, dtype=np.float32)
+    assert len(obb.qhull_input(cube)) == len(cube)
+    keep = obb._PREFILTER
+    try:
+        obb._PREFILTER = False
+        assert len(obb.qhull_input(tower)) == len(tower)
+    finally:
+        obb._PREFILTER = keep
+
+
+def test_strip_representatives_agree_between_tiles_far_from_the_origin():
+    """Both neighbours of a tile edge publish one (global row, local cluster) pair per lattice cell of the strip around
+    the edge; because the lattice is anchored at the frame's origin - not at a tile's own box - the two name the same rows
+    whatever else each tile holds, also 2.4e6 m from the origin (where the float32 'centroid' of a 100 M-point EPSG-scale
+    cloud puts the centred frame), and both strips of a tile come out of one pass."""
+    import torch
+    from pointcloudhookup_amd import tiles
+    rng = np.random.default_rng(8)
+    far = np.array([260000.0, 2435000.0, 40.0])
+    pts = (rng.uniform(0, 1, (6000, 3)) * [120.0, 60.0, 30.0] + far).astype(np.float32)
+    rows = np.arange(len(pts)) * 3 + 7                                  # global rows, ascending
+    core = rng.random(len(pts)) < 0.8
+    x = pts[:, 0]
+    e1, e2 = np.float32(far[0] + 40.0), np.float32(far[0] + 80.0)
+    left = np.flatnonzero(x < e1 + 17)                                   # tile 0: up to e1 (+ halo)
+    mid = np.flatnonzero((x >= e1 - 17) & (x < e2 + 17))                 # tile 1: [e1, e2) + halo
+
+    def reps(sel, strips):
+        lab = torch.from_numpy((rows[sel] % 5).astype(np.int64))
+        return tiles.strip_representatives(torch.from_numpy(pts[sel]), torch.from_numpy(rows[sel]), lab,
+                                           torch.from_numpy(core[sel]), strips, 8.0)
+
+    up0, = reps(left, [(float(e1) - 8.0, float(e1) + 8.0)])
+    lo1, up1 = reps(mid, [(float(e1) - 8.0, float(e1) + 8.0), (float(e2) - 8.0, float(e2) + 8.0)])
+    assert up0.shape[0] > 20 and torch.equal(up0[:, 0], lo1[:, 0])      # the same rows on either side of the edge
+    assert torch.equal(up0[:, 1], lo1[:, 1])                            # (labels here are a function of the row)
+    strip = core & (x >= np.float32(float(e1) - 8.0)) & (x < np.float32(float(e1) + 8.0))
+    side = 8.0 / 3 ** 0.5 * (1.0 - 2.0 ** -16)
+    cells = np.floor(pts[strip].astype(np.float64) / side).astype(np.int64)
+    want = {}
+    for r, c in zip(rows[strip], map(tuple, cells)):
+        want[c] = min(want.get(c, r), r)
+    assert sorted(want.values()) == up0[:, 0].tolist()                  # the smallest row of every cell, nothing else
+    assert up1.shape[0] > 20 and set(up1[:, 0].tolist()).isdisjoint(lo1[:, 0].tolist())
+    assert tiles.strip_representatives(torch.from_numpy(pts), torch.from_numpy(rows), torch.zeros(len(pts), dtype=torch.int64),
+                                       torch.zeros(len(pts), dtype=torch.bool), [(0.0, 1e9)], 8.0)[0].shape == (0, 2)
+    with pytest.raises(ValueError):
+        reps(left, [(0.0, 1.0), (2.0, 3.0), (4.0, 5.0)])
