@@ -275,6 +275,22 @@ int pch_dbscan_pair_stats(int64_t n, uint64_t* out4_host, void* ws, size_t ws_by
 int pch_dbscan_strip_pairs_i32(int64_t n, float x_lo, float x_hi, int32_t cap, int32_t* out_pairs,
                                int32_t* out_count, void* ws, size_t ws_bytes, void* stream);
 
+/* One representative per LATTICE cell of up to two strips of a tile: the smallest row among the core points of the
+ * cell whose x lies in the strip.  The lattice is shared by all ranks (cell = floor(coordinate / side) per axis, side =
+ * eps / sqrt(3) * (1 - 2^-16), anchored at the origin of the common frame), so the two tiles on either side of an edge
+ * name the SAME rows for the strip around it - the join on the row links their cluster pieces (tiles.cluster_tiled).
+ * xyz [n,3] float32, rows [n] int64 (global row of every point, ascending), labels [n] int32 (-1 = noise), core [n]
+ * uint8 - all device; strips_host [nstrips][2] float32 = x_from, x_to per strip (nstrips <= 2, disjoint).
+ * out_rows [2][cap] int64, out_labels [2][cap] int32: the pairs of strip k in row k, in no particular order;
+ * out_count [4] int32 (device): [k] = cells of strip k (may exceed cap: call again with a larger cap), [2] = flags
+ * (1: a coordinate beyond 2^20 cells from the origin, 2: table full - both make the result unusable), [3] = 0.
+ * Generalises: the per-chunk label offsets of utils/tower_extraction.py:113-116 to tiles that share points. */
+size_t pch_strip_lattice_reps_ws_bytes(int32_t cap);
+int pch_strip_lattice_reps_f32(const float* xyz, const int64_t* rows, const int32_t* labels, const uint8_t* core,
+                               int64_t n, int32_t nstrips, const float* strips_host, double eps, int32_t cap,
+                               int64_t* out_rows, int32_t* out_labels, int32_t* out_count,
+                               void* ws, size_t ws_bytes, void* stream);
+
 /* First row of xyz [n,3] float32 that holds NaN or +-inf, -1 if every row is finite.
  * Replaces: sklearn's input validation inside DBSCAN.fit (check_array, ensure_all_finite), which
  * is what makes a chunk "fail" in the reference (utils/tower_extraction.py:107-119).

@@ -59,6 +59,8 @@ _SIGS = {
     "pch_dbscan_set_pair_counting": (None, [C.c_int]),
     "pch_dbscan_pair_stats": (C.c_int, [_i64, _vp, _vp, _sz, _vp]),
     "pch_dbscan_strip_pairs_i32": (C.c_int, [_i64, _f32, _f32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "pch_strip_lattice_reps_ws_bytes": (_sz, [_i32]),
+    "pch_strip_lattice_reps_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _f64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pch_dbscan_ws_bytes": (_sz, [_i64]),
     "pch_dbscan_f32": (C.c_int, [_vp, _i64, _f64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pch_segment_by_label_ws_bytes": (_sz, [_i64, _i32]),

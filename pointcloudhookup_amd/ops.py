@@ -472,6 +472,55 @@ def tower_clusters(raw, eps=8.0, min_samples=80, chunk_size=50000, pct=25.0, off
     return ground, labels[:nf], k, perm[:nf], offsets[:k + 1], stats[:k]
 
 
+def strip_lattice_reps(xyz, rows, labels, core, strips, eps, cap=4096):
+    """One (global row, local cluster) pair per lattice cell of every strip (x_from, x_to) of ``strips`` (at most two):
+    the smallest row among the cell's core points with x in the strip (pch_strip_lattice_reps_f32; the lattice is
+    anchored at the frame's origin, so neighbouring tiles name the same rows).  xyz float32 [n,3], rows int64 [n]
+    ascending, labels int32 [n], core bool / uint8 [n] - device tensors.  Returns a list of int64 [m,2] tensors (row,
+    label), sorted by row, one per strip.  Synchronises (reads the counts)."""
+    import ctypes as C
+    import numpy as np
+    L = _lib.lib()
+    xyz = _need_cuda(xyz, torch.float32, "xyz").reshape(-1, 3)
+    rows = _need_cuda(rows, torch.int64, "rows")
+    labels = _need_cuda(labels, torch.int32, "labels")
+    core = core.contiguous()
+    if not core.is_cuda or core.dtype not in (torch.bool, torch.uint8):
+        raise TypeError("core must be a bool / uint8 CUDA/HIP tensor (no CPU fallback in the product path)")
+    core = core.view(torch.uint8)
+    n, dev = xyz.shape[0], xyz.device
+    if len(strips) > 2:
+        raise ValueError("at most two strips per call")
+    if not (rows.numel() == labels.numel() == core.numel() == n):
+        raise ValueError("rows / labels / core must have one entry per point")
+    flat = (C.c_float * (2 * max(len(strips), 1)))()
+    for k, (a, b) in enumerate(strips):
+        flat[2 * k], flat[2 * k + 1] = float(np.float32(a)), float(np.float32(b))
+    cap = int(cap)
+    with torch.cuda.device(dev):
+        while True:
+            out_rows = torch.empty((2, max(cap, 1)), dtype=torch.int64, device=dev)
+            out_lab = torch.empty((2, max(cap, 1)), dtype=torch.int32, device=dev)
+            cnt = torch.empty((4,), dtype=torch.int32, device=dev)
+            ws = _workspace(L.pch_strip_lattice_reps_ws_bytes(cap), dev)
+            _lib.check(L.pch_strip_lattice_reps_f32(_ptr(xyz), _ptr(rows), _ptr(labels), _ptr(core), n, len(strips),
+                                                    C.cast(flat, C.c_void_p), float(eps), cap, _ptr(out_rows),
+                                                    _ptr(out_lab), _ptr(cnt), _ptr(ws), ws.numel(), _stream()))
+            c = cnt.cpu().tolist()
+            if c[2] & 1:
+                raise ValueError("strip_lattice_reps: coordinates beyond 2^20 lattice cells from the origin")
+            need = max(c[0], c[1])
+            if need <= cap and not (c[2] & 2):
+                break
+            cap = max(2 * cap, need)                       # a strip with more cells than the buffer: once more
+    out = []
+    for k in range(len(strips)):
+        r, lab = out_rows[k, :c[k]], out_lab[k, :c[k]].to(torch.int64)
+        order = torch.argsort(r)
+        out.append(torch.stack([r[order], lab[order]], dim=1))
+    return out
+
+
 # ---------------------------------------------------------------------------- stage D0
 def segment_by_label(labels, xyz, nclusters):
     """Returns (perm int32 [n], offsets int64 [K+1], stats f32 [K,8] (min xyz, max xyz, 0, 0))."""

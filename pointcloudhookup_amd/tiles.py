@@ -360,13 +360,18 @@ def strip_representatives(points, rows, labels, core, strips, eps):
     both hold the points of such a strip, with the same core flags, name the SAME rows: the smallest global core row of
     every cell.  Two points of one cell are closer than eps, so the core points of a cell are one cluster in either
     tile.  The strips must not overlap (a tile is at least one halo wide).
-    points [n,3] float32, rows [n] int64 ascending, labels [n] int64, core [n] bool (same device).
+    points [n,3] float32, rows [n] int64 ascending, labels [n] int32 / int64, core [n] bool (same device).
     Returns a list of int64 [m,2] tensors sorted by row, one per strip (all strips in ONE pass: three host reads)."""
     none = torch.zeros((0, 2), dtype=torch.int64, device=points.device)
     if not strips:
         return []
     if len(strips) > 2:
         raise ValueError("strip_representatives: at most two strips per call")
+    if points.is_cuda:                                    # the product path: one table-building kernel + one that emits
+        from . import ops
+        return ops.strip_lattice_reps(points, rows, labels.to(torch.int32), core, strips, eps)
+    # CPU tensors (the gloo tests with a CPU stand-in for the fit): the same cells with torch operators
+    labels = labels.to(torch.int64)
     x = points[:, 0]
     sid = torch.full((points.shape[0],), -1, dtype=torch.int64, device=points.device)
     for k, (a, b) in enumerate(strips):
@@ -378,7 +383,7 @@ def strip_representatives(points, rows, labels, core, strips, eps):
     side = float(eps) / 3 ** 0.5 * (1.0 - 2.0 ** -16)
     # 21 bits per axis: +-2^20 cells = +-4.8e6 m at eps = 8 m (the centred frame of an EPSG-scale cloud lies up to
     # ~2.5e6 m from its origin: the float32 sequential "centroid" is that far off, utils/tower_extraction.py:63)
-    c = torch.floor(points.index_select(0, idx).to(torch.float64) / side).to(torch.int64) + (1 << 20)
+    c = torch.floor(points.index_select(0, idx).to(torch.float64) * (1.0 / side)).to(torch.int64) + (1 << 20)
     if bool(((c < 0) | (c >= (1 << 21))).any()):                          # host read 2
         raise ValueError("strip_representatives: coordinates beyond 2^20 lattice cells from the origin")
     sk = sid.index_select(0, idx)
@@ -528,7 +533,7 @@ def cluster_tiled(points, rows, own, x_lo, x_hi, eps, min_samples, halo=None, fi
     if rank < world - 1:
         strips.append((float(x_hi) - float(eps), float(x_hi) + float(eps)))
         which.append("upper")
-    reps = dict(zip(which, strip_representatives(pts_t, rows_d, lab_d, core_d, strips, eps)))
+    reps = dict(zip(which, strip_representatives(pts_t, rows_d, torch.as_tensor(labels).to(wdev), core_d, strips, eps)))
     lower, upper = reps.get("lower", none), reps.get("upper", none)
     _mark(timings, "pairs_built")
     got, _, words = _exchange([k, 2 * int(lower.shape[0]), 2 * int(upper.shape[0])],

@@ -557,3 +557,42 @@ def test_voxel_then_towers_hand_off_without_rereading_the_file(cuda, config1_las
     _towers_equal(want, te.extract_towers(other, log_callback=lambda m: None))
     assert len(reads) == n_reads + 1
     assert resident.take(out) is not None                              # still registered (and now consumed)
+
+
+def test_strip_lattice_reps_kernel_equals_the_torch_statement(cuda):
+    """pch_strip_lattice_reps_f32 (hash table of lattice cells, atomicMin of the row) against tiles.strip_representatives
+    on CPU tensors (torch operators): the same (row, label) pairs for one and two strips, 2.4e6 m from the origin, with a
+    pair buffer that is too small at first, and nothing for strips without core points."""
+    from pointcloudhookup_amd import tiles
+    rng = np.random.default_rng(18)
+    far = np.array([260000.0, 2435000.0, 40.0])
+    pts = np.vstack([rng.uniform(0, 1, (200_000, 3)) * [400.0, 100.0, 40.0],
+                     rng.normal([150.0, 50.0, 20.0], [2.5, 2.5, 9.0], (60_000, 3))]) + far
+    pts = pts[rng.permutation(len(pts))].astype(np.float32)
+    rows = np.cumsum(rng.integers(1, 4, len(pts))).astype(np.int64)        # ascending global rows with gaps
+    core = rng.random(len(pts)) < 0.7
+    labels = np.where(rng.random(len(pts)) < 0.9, rng.integers(0, 50, len(pts)), -1).astype(np.int32)
+    e1, e2 = float(np.float32(far[0] + 150.0)), float(np.float32(far[0] + 300.0))
+    for strips in ([(e1 - 8.0, e1 + 8.0)], [(e1 - 8.0, e1 + 8.0), (e2 - 8.0, e2 + 8.0)], [(0.0, 1.0)]):
+        want = tiles.strip_representatives(torch.from_numpy(pts), torch.from_numpy(rows),
+                                           torch.from_numpy(labels.astype(np.int64)), torch.from_numpy(core), strips, 8.0)
+        for cap in (4096, 16):                                           # 16: overflows, the call repeats itself
+            got = ops.strip_lattice_reps(torch.from_numpy(pts).to(cuda), torch.from_numpy(rows).to(cuda),
+                                         torch.from_numpy(labels).to(cuda), torch.from_numpy(core).to(cuda), strips, 8.0,
+                                         cap=cap)
+            assert len(got) == len(want)
+            for g, w in zip(got, want):
+                assert torch.equal(g.cpu(), w), (strips, cap, g.shape, w.shape)
+    assert want[0].shape[0] == 0
+    # through the dispatcher: device tensors take the kernel
+    got = tiles.strip_representatives(torch.from_numpy(pts).to(cuda), torch.from_numpy(rows).to(cuda),
+                                      torch.from_numpy(labels.astype(np.int64)).to(cuda), torch.from_numpy(core).to(cuda),
+                                      [(e1 - 8.0, e1 + 8.0)], 8.0)
+    want = tiles.strip_representatives(torch.from_numpy(pts), torch.from_numpy(rows),
+                                       torch.from_numpy(labels.astype(np.int64)), torch.from_numpy(core),
+                                       [(e1 - 8.0, e1 + 8.0)], 8.0)
+    assert want[0].shape[0] > 100 and torch.equal(got[0].cpu(), want[0])
+    with pytest.raises(ValueError):
+        ops.strip_lattice_reps(torch.from_numpy(pts * 10).to(cuda), torch.from_numpy(rows).to(cuda),
+                               torch.from_numpy(labels).to(cuda), torch.from_numpy(core).to(cuda),
+                               [(0.0, 1e9)], 8.0)                       # 2.4e7 m from the origin: beyond the lattice

@@ -851,7 +851,7 @@ def test_strip_representatives_agree_between_tiles_far_from_the_origin():
     assert torch.equal(up0[:, 1], lo1[:, 1])                            # (labels here are a function of the row)
     strip = core & (x >= np.float32(float(e1) - 8.0)) & (x < np.float32(float(e1) + 8.0))
     side = 8.0 / 3 ** 0.5 * (1.0 - 2.0 ** -16)
-    cells = np.floor(pts[strip].astype(np.float64) / side).astype(np.int64)
+    cells = np.floor(pts[strip].astype(np.float64) * (1.0 / side)).astype(np.int64)
     want = {}
     for r, c in zip(rows[strip], map(tuple, cells)):
         want[c] = min(want.get(c, r), r)
