@@ -805,3 +805,37 @@ def test_percentile_bracketed_select_is_exact(cuda, case, q):
     want = np.float32(np.percentile(z, q))
     got = ops.percentile_f32(_dev(z, cuda), q).cpu().numpy()[0]
     assert (np.isnan(want) and np.isnan(got)) or got.view(np.uint32) == want.view(np.uint32), (case, q, got, want)
+
+
+def test_voxel_scatter_staged_through_lds_equals_the_direct_form(cuda):
+    """Large inputs take the partition whose tiles are put in digit order inside LDS before they are copied out
+    (vx_scatter_lds_k; chosen by size, PCH_VX_SCATTER=lds forces it).  A child process with the switch set runs ragged
+    tiles, two chunks with a dense column, and a 3 M-row corridor against the oracle (set equality per chunk)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from oracle import voxel as ovx
+from pointcloudhookup_amd import ops, synth
+rng = np.random.default_rng(77)
+OFF = np.asarray(synth.GLOBAL_OFFSET, dtype=np.float64)
+g = np.column_stack([rng.uniform(0, 50, 150000), rng.uniform(0, 100, 150000), rng.normal(0, 0.05, 150000)])
+t = rng.normal([25, 50, 22], [2.5, 2.5, 9], (150000, 3))
+tower = np.vstack([g, t])
+cases = [(rng.random((50001, 3)) * [50.0, 20.0, 5.0] + OFF, 0.25, 12345),
+         (tower[rng.permutation(len(tower))] + OFF, 0.2, 200000),
+         (synth.corridor_numpy(3_000_000, seed=synth.SEED0 + 9, kind="corridor", offset=True, towers=6), 0.1, 500000)]
+for pts, voxel, chunk in cases:
+    idx, mean, count, offs = ops.voxel_downsample(torch.from_numpy(np.ascontiguousarray(pts)).cuda(), voxel, chunk)
+    ridx, rmean, rcount, roffs = ovx.voxel_down_sample_chunked(pts, voxel, chunk)
+    assert np.array_equal(offs.cpu().numpy(), roffs)
+    gi, gm, gc = ovx.canonical(idx.cpu().numpy(), mean.cpu().numpy(), count.cpu().numpy(), roffs)
+    assert np.array_equal(gi, ridx) and np.array_equal(gc, rcount) and np.array_equal(gm.view(np.uint64), rmean.view(np.uint64))
+print("staged scatter ok", len(cases))
+'''
+    env = dict(os.environ, PCH_VX_SCATTER="lds")
+    r = subprocess.run([sys.executable, "-c", script, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "staged scatter ok 3" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
