@@ -303,7 +303,7 @@ __global__ __launch_bounds__(VP_MAXBINS) void vx_binscan_k(VoxelPlan g, uint32_t
 // <= VF_CAP rows that come out of it are contiguous there and are finished like any other batch.  (Until round 4 every
 // part swept the whole unit twice and picked its rows: 12 sweeps of a 20 000-row unit that was cut into six.)
 constexpr int VS_THREADS = 1024, VS_WAVES = VS_THREADS / 64, VS_ROUNDS = 4, VS_TILE = VS_THREADS * VS_ROUNDS;
-__global__ __launch_bounds__(VS_THREADS) void vx_split_k(VoxelPlan g, const double* __restrict__ minb,
+__global__ __launch_bounds__(VS_THREADS, 8) void vx_split_k(VoxelPlan g, const double* __restrict__ minb,
                                                        const Row* __restrict__ rows, Row* __restrict__ rows_b,
                                                        VoxelBatch* __restrict__ batches,
                                                        const VoxelOversize* __restrict__ over,
@@ -1291,7 +1291,7 @@ extern "C" int pch_voxel_downsample_f64(const double* xyz, int64_t n, double vox
                (const uint32_t*)w.tile_hist, (const uint32_t*)w.unit_start, w.bufA);
     {   // units above the LDS capacity (dense columns): split by their next digit, one workgroup each
         int64_t sg = nchunks * g.nb;
-        if (sg > 512) sg = 512;
+        if (sg > 2048) sg = 2048;                          // one unit per workgroup as a rule: 512 of them are resident at a time
         PCH_LAUNCH("voxel_split", vx_split_k, dim3((unsigned)sg), dim3(VS_THREADS), 0, s, g, (const double*)w.minb,
                    (const Row*)w.bufA, w.bufB, w.batches, (const VoxelOversize*)w.over, (const uint32_t*)w.nover);
     }
