@@ -61,7 +61,10 @@ names = {"ms_summary_k": "mean_summary", "ms_walk_k": "mean_walk", "ms_level2_k"
          "db_union_face_k": "db_union0", "db_rowtab_k": "db_rowtab", "db_cellstats_k": "db_cellstats",
          "db_cells_k": "db_cells", "ms_sample_k": "mean_sample", "ms_prefix_k": "mean_prefix",
          "scan1_k<false>": "scan1", "scan1_k<true>": "scan1_popc", "db_prelabel_k": "db_prelabel",
-         "sl_hist_k": "seg_hist", "sl_scatter_k": "seg_scatter", "sl_offsets_k": "seg_offsets"}
+         "sl_hist_k": "seg_hist", "sl_scatter_k": "seg_scatter", "sl_offsets_k": "seg_offsets",
+         "vx_finish_k": "voxel_finish", "vx_scatter_k": "voxel_scatter", "vx_scatter_lds_k": "voxel_scatter",
+         "vx_tilehist_k": "voxel_tilehist", "vx_minmax_k": "voxel_minmax", "vx_split_k": "voxel_split",
+         "vx_binscan_k": "voxel_binscan"}
 sys.path.insert(0, here)
 from stamp import csrc_sha            # noqa: E402
 traffic = {"points": int(points), "kind": kind, "frame": frame, "source": tag, "csrc_sha": csrc_sha(),
