@@ -37,8 +37,6 @@ struct DbGrid {
     const uint32_t* chunk_bad;   // != 0: the chunk holds NaN/inf and stays noise as a whole
     const uint32_t* chunk_cells; // [chunks + 1] first cell of every chunk (cells are sorted by chunk first)
     int     min_samples;
-    int     geom;                // 1: cell (cx,cy,cz) is the cube origin + (c .. c+1) * cell (not so with compressed
-                                 // coordinates): kernels may skip whole neighbour runs by their distance to a query
 };
 
 // (dy,dz) rows ordered by distance so that early exits trigger as soon as possible
@@ -758,30 +756,6 @@ __global__ __launch_bounds__(DB_THREADS) void db_rowtab_k(DbGrid g, const uint64
     rowtab[(int64_t)c * DB_ROWS + l] = v;
 }
 
-// ---- can candidate segment r of query cell (cx,cy,cz) hold a point within eps of q? -----------------------------
-// The 43 candidate segments of db_core_k are runs of cells of one (dy,dz) row: r < 9: x-1..x+1 of inner row r; 9..17:
-// the x-2 cell of inner row r-9; 18..26: the x+2 cell of inner row r-18; 27..42: x-2..x+2 of outer row r-18.  A cell is
-// the cube origin + (c .. c+1) * side up to the rounding of the index product (< 2^-21 cells): the box is taken 2^-10
-// cells wider on every side.  db_box_d2 never exceeds the computed distance to any point inside the box, so a segment
-// with db_box_d2 > eps^2 holds no neighbour of q: skipping it is exact.  For a query near the far side of its cell this
-// removes most of the 5x5x5 block's outer shell - where a sparse cell beside a tower core finds its largest runs.
-__device__ __forceinline__ bool db_seg_near(const DbGrid& g, int cx, int cy, int cz, int r, const float4& q) {
-    const int l = r < 9 ? r : (r < 18 ? r - 9 : r - 18);
-    const int xa = r < 9 ? cx - 1 : (r < 18 ? cx - 2 : (r < 27 ? cx + 2 : cx - 2));
-    const int xb = r < 9 ? cx + 1 : (r < 18 ? cx - 2 : cx + 2);
-    const int ny = cy + DB_ROW_DY[l], nz = cz + DB_ROW_DZ[l];
-    const double m = 1.0 / 1024.0;
-    float box[6];
-    // rounded outwards: a float box that contains the double one
-    box[0] = __double2float_rd((double)g.ox + ((double)xa - m) * g.cell);
-    box[3] = __double2float_ru((double)g.ox + ((double)xb + 1.0 + m) * g.cell);
-    box[1] = __double2float_rd((double)g.oy + ((double)ny - m) * g.cell);
-    box[4] = __double2float_ru((double)g.oy + ((double)ny + 1.0 + m) * g.cell);
-    box[2] = __double2float_rd((double)g.oz + ((double)nz - m) * g.cell);
-    box[5] = __double2float_ru((double)g.oz + ((double)nz + 1.0 + m) * g.cell);
-    return !(db_box_d2(q, box) > g.eps2);
-}
-
 // ---- core points ---------------------------------------------------------------------
 // one wave per cell.  Dense cell: all core.  Sparse cell: n-body tile loop - every lane owns one
 // query point of the cell, candidate tiles (64 points of the sorted neighbour runs) are staged
@@ -842,13 +816,9 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
     // nine nearest runs), then the x-2 / x+2 ends of those runs, then the sixteen outer runs
     uint32_t* sa = seg_a[wave_id()];
     uint32_t* sb = seg_b[wave_id()];
-    int qcx = 0, qcy = 0, qcz = 0;                         // the query cell's coordinates (db_seg_near)
     {
         const uint64_t xmask = (1ull << g.bx) - 1;
         const int cx = (int)(cell_key[c] & xmask);
-        qcx = cx;
-        qcy = (int)((cell_key[c] >> g.bx) & ((1ull << g.by) - 1));
-        qcz = (int)((cell_key[c] >> (g.bx + g.by)) & ((1ull << g.bz) - 1));
         if (l < DB_ROWS) {
             const int ca = rs->ca[l], cb = rs->cb[l];
             if (l < 9) {
@@ -875,7 +845,6 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
             int count = 0;
             for (int r = 0; r < DB_SEGS && count < g.min_samples; ++r) {
                 const uint32_t pa = sa[r], pb = sb[r];
-                if (pa >= pb || (g.geom && pb - pa >= 64u && !db_seg_near(g, qcx, qcy, qcz, r, qp))) continue;
                 for (uint32_t j0 = pa; j0 < pb && count < g.min_samples; j0 += 64) {
                     const uint32_t j = j0 + l;
                     bool hit = false;
@@ -907,13 +876,6 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
         while (r < DB_SEGS && __popcll(active) >= DB_FEW_QUERIES / 2) {
             const uint32_t pb = sb[r];
             if (j0 >= pb) { ++r; if (r < DB_SEGS) j0 = sa[r]; continue; }
-            // a run that none of the queries still counting can reach (tested once, where it starts)
-            if (g.geom && j0 == sa[r] && pb - j0 >= 64u &&
-                __ballot(valid && count < g.min_samples && db_seg_near(g, qcx, qcy, qcz, r, Q)) == 0) {
-                ++r;
-                if (r < DB_SEGS) j0 = sa[r];
-                continue;
-            }
             const int nj = (int)((pb - j0) < 64u ? (pb - j0) : 64u);
             float4 P;
             P.x = P.y = P.z = 3.0e38f; P.w = 0.0f;         // padding: squared distance overflows to +inf
@@ -942,12 +904,6 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
             while (rr < DB_SEGS && cq < g.min_samples) {
                 const uint32_t pb = sb[rr];
                 if (jj >= pb) { ++rr; if (rr < DB_SEGS) jj = sa[rr]; continue; }
-                // a long run this query cannot reach: skipped whole (tested where the run starts, or resumes)
-                if (g.geom && pb - jj >= 64u && (jj == sa[rr] || jj == j0) && !db_seg_near(g, qcx, qcy, qcz, rr, qp)) {
-                    ++rr;
-                    if (rr < DB_SEGS) jj = sa[rr];
-                    continue;
-                }
                 const uint32_t j = jj + l;
                 bool hit = false;
                 if (j < pb) hit = db_within2(qp, pts[j], g);
@@ -1949,7 +1905,6 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
     g.chunk_bad = w.chunk_bad;
     g.chunk_cells = w.chunk_cells;
     g.min_samples = min_samples;
-    g.geom = 1;
     double ext[3];
     int mc[3] = {0, 0, 0};
     bool overflow = false;
@@ -1989,7 +1944,6 @@ int pch::dbscan_run(const float* xyz, int64_t n, double eps, int32_t min_samples
             return PCH_OK;
         }
         compressed = true;
-        g.geom = 0;
         int64_t* first_bad = reinterpret_cast<int64_t*>(w.meta + 12);
         PCH_HIP_TRY(hipMemsetAsync(first_bad, 0xFF, sizeof(int64_t), s));
         PCH_LAUNCH("db_first_bad", db_first_bad_k, dim3((unsigned)gstride), dim3(DB_THREADS), 0, s, xyz, n,
