@@ -241,16 +241,41 @@ inline bool reduce_for_qhull(const T* pts, int64_t n, double* out, int64_t* out_
     if (n < 64) return all();
     int64_t mp[6];
     double lo[3], hi[3];
-    for (int k = 0; k < 3; ++k) {
-        int64_t imin = 0, imax = 0;
-        double vmin = (double)pts[k], vmax = vmin;
-        for (int64_t i = 1; i < n; ++i) {
-            const double v = (double)pts[3 * i + k];
-            if (v < vmin) { vmin = v; imin = i; }          // strict: the first occurrence stays
-            if (v > vmax) { vmax = v; imax = i; }
+    {
+        // the extreme VALUES in one sweep the compiler can vectorise (48 independent lanes over the flat array: lane
+        // j holds coordinate j % 3), then the FIRST row holding each of them - qhull's strict comparisons keep the
+        // first occurrence
+        constexpr int LANES = 48;
+        T mn[LANES], mx[LANES];
+        const int64_t flat = 3 * n;
+        for (int j = 0; j < LANES; ++j) { mn[j] = pts[j % 3]; mx[j] = pts[j % 3]; }
+        int64_t i = 0;
+        for (; i + LANES <= flat; i += LANES)
+            for (int j = 0; j < LANES; ++j) {
+                const T v = pts[i + j];
+                mn[j] = v < mn[j] ? v : mn[j];
+                mx[j] = v > mx[j] ? v : mx[j];
+            }
+        for (; i < flat; ++i) {
+            const T v = pts[i];
+            const int j = (int)(i % 3);
+            mn[j] = v < mn[j] ? v : mn[j];
+            mx[j] = v > mx[j] ? v : mx[j];
         }
-        if (!(vmax > vmin) || !(fabs(vmax) < INFINITY) || !(fabs(vmin) < INFINITY)) return all();
-        mp[2 * k] = imin; mp[2 * k + 1] = imax; lo[k] = vmin; hi[k] = vmax;
+        for (int k = 0; k < 3; ++k) {
+            T a = mn[k], b = mx[k];
+            for (int j = k; j < LANES; j += 3) { a = mn[j] < a ? mn[j] : a; b = mx[j] > b ? mx[j] : b; }
+            lo[k] = (double)a; hi[k] = (double)b;
+            if (!(hi[k] > lo[k]) || !(fabs(hi[k]) < INFINITY) || !(fabs(lo[k]) < INFINITY)) return all();
+            int64_t imin = -1, imax = -1;
+            for (int64_t r = 0; r < n && (imin < 0 || imax < 0); ++r) {
+                const T v = pts[3 * r + k];
+                if (imin < 0 && v == a) imin = r;
+                if (imax < 0 && v == b) imax = r;
+            }
+            if (imin < 0 || imax < 0) return all();        // (cannot happen: the values were read from these rows)
+            mp[2 * k] = imin; mp[2 * k + 1] = imax;
+        }
     }
     double q[6][3];
     for (int i = 0; i < 6; ++i)
@@ -300,15 +325,24 @@ inline bool reduce_for_qhull(const T* pts, int64_t n, double* out, int64_t* out_
     inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det; inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
     inv[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) / det; inv[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det;
     inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
+    // blocks of rows: the inside test as a branch-free sweep into flags, then the rows that stay are copied
     int64_t kept = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        const double x = (double)pts[3 * i], y = (double)pts[3 * i + 1], z = (double)pts[3 * i + 2];
-        const double dx = x - t0[0], dy = y - t0[1], dz = z - t0[2];
-        const double b0 = inv[0][0] * dx + inv[0][1] * dy + inv[0][2] * dz;
-        const double b1 = inv[1][0] * dx + inv[1][1] * dy + inv[1][2] * dz;
-        const double b2 = inv[2][0] * dx + inv[2][1] * dy + inv[2][2] * dz;
-        const bool inside = b0 > 1e-6 && b1 > 1e-6 && b2 > 1e-6 && (b0 + b1 + b2) < 1.0 - 1e-6;
-        if (!inside) { out[3 * kept] = x; out[3 * kept + 1] = y; out[3 * kept + 2] = z; ++kept; }
+    constexpr int BLOCK = 512;
+    unsigned char in[BLOCK];
+    for (int64_t r0 = 0; r0 < n; r0 += BLOCK) {
+        const int m = (int)(n - r0 < BLOCK ? n - r0 : BLOCK);
+        const T* p = pts + 3 * r0;
+        for (int i = 0; i < m; ++i) {
+            const double dx = (double)p[3 * i] - t0[0], dy = (double)p[3 * i + 1] - t0[1], dz = (double)p[3 * i + 2] - t0[2];
+            const double b0 = inv[0][0] * dx + inv[0][1] * dy + inv[0][2] * dz;
+            const double b1 = inv[1][0] * dx + inv[1][1] * dy + inv[1][2] * dz;
+            const double b2 = inv[2][0] * dx + inv[2][1] * dy + inv[2][2] * dz;
+            in[i] = (unsigned char)((b0 > 1e-6) & (b1 > 1e-6) & (b2 > 1e-6) & ((b0 + b1 + b2) < 1.0 - 1e-6));
+        }
+        for (int i = 0; i < m; ++i) {
+            out[3 * kept] = (double)p[3 * i]; out[3 * kept + 1] = (double)p[3 * i + 1]; out[3 * kept + 2] = (double)p[3 * i + 2];
+            kept += 1 - in[i];                              // an inside row is overwritten by the next one
+        }
     }
     *out_rows = kept;
     return kept < n;

@@ -154,15 +154,62 @@ def _prefilter_ok():
         return False
 
 
+# ---- the qhull call itself ------------------------------------------------------------------------------------
+# scipy.spatial.ConvexHull spends a quarter of a 43 000-point call OUTSIDE qhull (neighbour / coplanar / good arrays,
+# strided min/max bounds of the input, a second copy of the points): _hull_simplices drives the same compiled object
+# (scipy.spatial._qhull._Qhull - the class ConvexHull itself instantiates, same options, same qhull run) and takes only
+# the triangle list.  _Qhull is scipy-private, so the short cut is taken only where it is found AND has reproduced
+# ConvexHull's triangles on a check cloud in this process; anything else (another scipy, an exception) and ConvexHull
+# is called as before.  PCH_OBB_BARE_QHULL=0 switches it off.
+_BARE = None
+_OPTS = "QbB Pp Qt"
+
+
+def _bare_simplices(p):
+    from scipy.spatial import _qhull
+    q = _qhull._Qhull(b"i", p, _OPTS.encode(), required_options=b"Qt", incremental=False)
+    try:
+        q.triangulate()
+        return q.get_simplex_facet_array()[0]
+    finally:
+        q.close()
+
+
+def _bare_ok():
+    try:
+        rng = np.random.default_rng(20261005)
+        for n in (300, 20000):
+            c = np.ascontiguousarray((rng.normal(size=(n, 3)) * [2.5, 3.5, 9.0]).astype(np.float32), dtype=np.float64)
+            want = ConvexHull(c, qhull_options=_OPTS)
+            got = _bare_simplices(c)
+            if got.dtype != want.simplices.dtype or not np.array_equal(got, want.simplices):
+                return False
+        return True
+    except Exception:
+        return False
+
+
+def _hull_simplices(p):
+    """[nt,3] point indices of the hull triangles of float64 rows ``p``, qhull's order: ConvexHull(p, 'QbB Pp Qt')
+    .simplices (errors included - they are raised by the same constructor)"""
+    global _BARE
+    if _BARE is None:
+        import os
+        _BARE = os.environ.get("PCH_OBB_BARE_QHULL", "1") != "0" and _bare_ok()
+    if _BARE and p.ndim == 2 and p.shape[1] == 3 and p.dtype == np.float64 and p.flags.c_contiguous:
+        return _bare_simplices(p)
+    return ConvexHull(p, qhull_options=_OPTS).simplices
+
+
 def hull_vertices_normals(points):
     """qhull ('QbB Pp Qt') hull: vertices in ascending input order + unit triangle normals."""
     p = qhull_input(points)
-    hull = ConvexHull(p, qhull_options="QbB Pp Qt")
-    keep = np.sort(hull.vertices)
+    simplices = _hull_simplices(p)
+    keep = np.unique(simplices)                           # = sort(ConvexHull.vertices)
     remap = np.zeros(len(p), dtype=np.int64)
     remap[keep] = np.arange(len(keep))
     v = p[keep]
-    tri = v[remap[hull.simplices]]
+    tri = v[remap[simplices]]
     n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
     ln = np.sqrt(np.einsum("ij,ij->i", n, n))
     ok = ln > _TOL
@@ -285,11 +332,11 @@ def bounding_box_oriented(points, extent_order="unsorted"):
 def _hull_triangles(points):
     """(hull vertices [nv,3] in ascending input order, triangles [nt,3] int32 into them, qhull's order)."""
     p = qhull_input(points)
-    hull = ConvexHull(p, qhull_options="QbB Pp Qt")
-    ids = np.sort(hull.vertices)
+    simplices = _hull_simplices(p)
+    ids = np.unique(simplices)
     remap = np.empty(len(p), dtype=np.int32)
     remap[ids] = np.arange(len(ids), dtype=np.int32)
-    return p[ids], remap[hull.simplices]
+    return p[ids], remap[simplices]
 
 
 # ---- many clusters at once -------------------------------------------------------------
@@ -361,13 +408,18 @@ def _boxed(args):
         return None, e
 
 
-def usable_cpus():
-    """cores this process may really use: affinity mask, cut by a cgroup CPU quota where one is readable"""
+def _affinity_cpus():
     import os
     try:
-        n = len(os.sched_getaffinity(0))
+        return max(1, len(os.sched_getaffinity(0)))
     except AttributeError:
-        n = os.cpu_count() or 1
+        return max(1, os.cpu_count() or 1)
+
+
+def cpu_quota():
+    """(cores, period in s) of the cgroup CPU quota this process runs under, or None where none is readable.  A quota
+    is a BUDGET - cores x period CPU-seconds per period, spent at any parallelism - not a core count: 16 cores /
+    100 ms lets 48 processes run for 33 ms and then freezes every thread of the group until the period ends."""
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
             txt = open(path).read().split()
@@ -375,22 +427,40 @@ def usable_cpus():
                 quota, period = txt[0], float(txt[1])
             else:
                 quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if quota not in ("max", "-1") and float(quota) > 0:
-                n = min(n, max(1, int(float(quota) / period + 0.5)))
-            break
+            if quota not in ("max", "-1") and float(quota) > 0 and period > 0:
+                return float(quota) / period, period / 1e6
+            return None
         except (OSError, ValueError, IndexError):
             continue
+    return None
+
+
+def usable_cpus():
+    """cores this process may use in the long run: affinity mask, cut by a cgroup CPU quota where one is readable"""
+    n = _affinity_cpus()
+    q = cpu_quota()
+    if q is not None:
+        n = min(n, max(1, int(q[0] + 0.5)))
     return max(1, n)
 
 
 POOL_CAP = 64         # worker processes at most (a 100 M-point tile has ~230 clusters; beyond ~4 per worker the tail idles)
+BURST = 2             # under a CPU quota: worker processes per quota core (see Pool._may_start)
 
 
 def default_workers():
-    """PCH_OBB_WORKERS, else one worker per usable core up to POOL_CAP"""
+    """PCH_OBB_WORKERS, else one worker per usable core up to POOL_CAP - and under a cgroup CPU quota BURST workers per
+    quota core where the machine has the cores: the table of ONE tile (~0.8 CPU-seconds) fits the budget of one quota
+    period, so it may be spent at twice the parallelism; the dispatcher keeps the pool inside the budget
+    (Pool._may_start), so a stream of tables still runs at the quota's pace without the group being frozen."""
     import os
     env = os.environ.get("PCH_OBB_WORKERS")
-    return max(1, int(env)) if env else min(POOL_CAP, usable_cpus())
+    if env:
+        return max(1, int(env))
+    n = usable_cpus()
+    if cpu_quota() is not None:
+        n = min(_affinity_cpus(), BURST * n)
+    return min(POOL_CAP, n)
 
 
 def _send(fh, obj):
@@ -473,7 +543,8 @@ class Job:
         self.results = [None] * ntasks
         self.left = ntasks
         self.done = threading.Event()
-        self.worker_s = 0.0                    # seconds the workers reported for this job's tasks (sum)
+        self.worker_s = 0.0                    # wall seconds the workers reported for this job's tasks (sum)
+        self.worker_cpu_s = 0.0                # ... and the CPU seconds of the same (less where a CPU quota throttles)
         self.t_submit = self.t_done = 0.0
         if ntasks == 0:
             self.done.set()
@@ -500,6 +571,8 @@ class _Proc:
         os.set_blocking(self.fd, False)
         self.buf = bytearray()
         self.task = None                       # (job, index, request) in flight
+        self.t_task = 0.0                      # when it was handed out
+        self.ready = False                     # its imports and self-checks are done (it said so)
         self.alive = True
 
 
@@ -519,6 +592,8 @@ class Pool:
         self.stopping = False
         self.thread = None
         self.buffers = []
+        self.quota = cpu_quota()               # (cores, period s) | None
+        self.spent = collections.deque()       # (when, CPU seconds) of the tasks finished lately
 
     # ---- workers
     def grow(self, n):
@@ -583,11 +658,51 @@ class Pool:
             job.t_done = time.perf_counter()
             job.done.set()
 
+    # ---- the CPU budget (only under a cgroup quota)
+    def _may_start(self, procs, now):
+        """may another task start now?  Always while fewer workers are busy than the quota has cores.  Beyond that
+        only while the CPU-seconds the pool has spent in the last quota period (finished tasks + the running ones so
+        far) leave room in the period's budget: a group that overdraws it is frozen - every thread of it, this
+        process's main thread and its HIP runtime threads included - until the period ends, which costs a stream of
+        tiles more than the extra workers gain.  (The kernel's periods are fixed windows of unknown phase; the sliding
+        window and the 0.8 allow for that and for what the parent itself burns.)"""
+        if self.quota is None:
+            return True
+        cores, period = self.quota
+        busy = [p for p in procs if p.alive and p.task is not None]
+        if len(busy) < max(1, int(cores) - 1):
+            return True
+        while self.spent and self.spent[0][0] < now - period:
+            self.spent.popleft()
+        used = sum(c for _, c in self.spent) + sum(min(now - p.t_task, period) for p in busy)
+        return used + 0.004 * (len(busy) + 1) < 0.8 * cores * period
+
+    def _hand_out(self, sel, procs):
+        """queued tasks to idle, ready workers; returns True when tasks are left over only for want of budget"""
+        import time
+        for p in procs:
+            if not p.alive or not p.ready or p.task is not None:
+                continue
+            now = time.perf_counter()
+            if not self._may_start(procs, now):
+                return bool(self.queue)
+            with self.lock:
+                item = self.queue.popleft() if self.queue else None
+            if item is None:
+                return False
+            try:
+                _send(p.proc.stdin, item[2])
+                p.task, p.t_task = item, now
+            except (OSError, ValueError):
+                self._dead(sel, p, item)
+        return False
+
     def _run(self):
         import os
         import pickle
         import selectors
         import struct
+        import time
         sel = selectors.DefaultSelector()
         sel.register(self.wake_r, selectors.EVENT_READ, None)
         known = set()
@@ -598,19 +713,7 @@ class Pool:
                 if p.alive and id(p) not in known:
                     known.add(id(p))
                     sel.register(p.fd, selectors.EVENT_READ, p)
-            # hand tasks to idle workers
-            for p in procs:
-                if not p.alive or p.task is not None:
-                    continue
-                with self.lock:
-                    item = self.queue.popleft() if self.queue else None
-                if item is None:
-                    break
-                try:
-                    _send(p.proc.stdin, item[2])
-                    p.task = item
-                except (OSError, ValueError):
-                    self._dead(sel, p, item)
+            waiting = self._hand_out(sel, procs)
             if not any(p.alive for p in procs):                  # nobody left: compute here
                 while True:
                     with self.lock:
@@ -618,7 +721,7 @@ class Pool:
                     if item is None:
                         break
                     self._finish(item[0], item[1], _answer(item[2])[0])
-            for key, _ in sel.select(timeout=0.5):
+            for key, _ in sel.select(timeout=0.002 if waiting else 0.5):
                 if key.data is None:
                     try:
                         os.read(self.wake_r, 4096)
@@ -640,20 +743,19 @@ class Pool:
                     (ln,) = struct.unpack_from("<I", p.buf, 0)
                     if len(p.buf) < 4 + ln:
                         break
-                    value, secs = pickle.loads(bytes(p.buf[4:4 + ln]))
+                    msg = pickle.loads(bytes(p.buf[4:4 + ln]))
                     del p.buf[:4 + ln]
+                    if isinstance(msg, str):                     # "ready": imports and self-checks done
+                        p.ready = True
+                        continue
+                    value, secs, cpu = msg
                     job, index, _ = p.task
                     p.task = None
                     job.worker_s += secs
+                    job.worker_cpu_s += cpu
+                    self.spent.append((time.perf_counter(), cpu))
                     self._finish(job, index, value)
-                    with self.lock:                              # next task at once, without another pass
-                        item = self.queue.popleft() if self.queue else None
-                    if item is not None:
-                        try:
-                            _send(p.proc.stdin, item[2])
-                            p.task = item
-                        except (OSError, ValueError):
-                            self._dead(sel, p, item)
+                self._hand_out(sel, procs)                       # next tasks at once, without another pass
 
     def _dead(self, sel, p, item):
         """a worker that went away: its task (if any) is computed in the dispatcher, the rest goes to the others"""
@@ -728,11 +830,11 @@ def _mapped(path, nbytes, ident):
 
 
 def _answer(req):
-    """one request -> ((value, exception | None), seconds).  Runs in a worker (or in the parent's dispatcher when
+    """one request -> ((value, exception | None), wall seconds, CPU seconds).  Runs in a worker (or in the parent's dispatcher when
     no worker is left).  Requests: ("shm", (path, nbytes, id), byte offset, rows, dtype, what) | ("inline", array,
     what)."""
     import time
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     try:
         if req[0] == "shm":
             _, where, off, rows, dtype, what = req
@@ -743,7 +845,7 @@ def _answer(req):
         out = _boxed((pts, what))
     except Exception as e:
         out = (None, e)
-    return out, time.perf_counter() - t0
+    return out, time.perf_counter() - t0, time.process_time() - c0
 
 
 def boxes_job(buf, offsets, dtype, extent_order="unsorted", workers=None, order=None):
@@ -876,7 +978,12 @@ if __name__ == "__main__":
     if "--worker" in sys.argv:
         inp, out = sys.stdin.buffer, sys.stdout.buffer
         sys.stdout = sys.stderr                # stray prints must not corrupt the answer stream
-        _hostlib()
+        try:                                   # the once-per-process checks now, not inside the first task
+            qhull_input(np.zeros((64, 3), dtype=np.float32))
+            _hull_simplices(np.ascontiguousarray(np.random.default_rng(0).normal(size=(16, 3))))
+        except Exception:
+            pass
+        _send(out, "ready")
         while True:
             head = inp.read(4)
             if len(head) < 4:

@@ -158,7 +158,8 @@ def _exact_finish(pl, buf, offsets, ev, k, centroid, extent_order, params, timin
     t3 = time.perf_counter()
     nw = max(pl.size(), 1)
     timings.update({"wait_gather_d2h_ms": 1e3 * (t1 - t0), "boxes_wall_ms": 1e3 * (t2 - t1),
-                    "boxes_worker_cpu_ms": 1e3 * job.worker_s, "workers": nw,
+                    "boxes_worker_wall_ms": 1e3 * job.worker_s, "boxes_worker_cpu_ms": 1e3 * job.worker_cpu_s,
+                    "workers": nw,
                     "worker_utilisation": round(job.worker_s / max((t2 - t1) * nw, 1e-9), 3),
                     "accept_and_copy_ms": 1e3 * (t3 - t2), "clustered_points": m,
                     "bytes_to_host": 12 * m, "buffer_pinned": bool(buf.pinned)})

@@ -791,6 +791,50 @@ def test_obb_pool_jobs_in_flight_shared_buffers_and_a_dead_worker():
     assert obb.usable_cpus() >= 1 and 1 <= obb.default_workers() <= max(obb.POOL_CAP, 1)
 
 
+def test_obb_pool_keeps_inside_a_cpu_quota_budget(monkeypatch):
+    """Under a cgroup CPU quota the pool holds more workers than the quota has cores (one tile's table fits one
+    period's budget), and the dispatcher starts a task beyond the quota's core count only while the period's budget has
+    room: the rule itself, on a pool without processes, and the quota parser."""
+    import collections
+    from pointcloudhookup_amd import obb
+
+    class P:
+        def __init__(self, t):
+            self.alive, self.ready, self.task, self.t_task = True, True, (None, 0, None), t
+
+    pl = obb.Pool()
+    pl.quota = None
+    assert pl._may_start([P(0.0)] * 100, 1.0)                         # no quota: no rule
+    pl.quota = (4.0, 0.1)                                             # 4 cores / 100 ms: 0.4 CPU-s per period
+    assert pl._may_start([P(0.99), P(0.99)], 1.0)                     # fewer busy than cores: always
+    fresh = [P(0.999)] * 6                                            # six just started: 0.006 + 0.028 < 0.32
+    assert pl._may_start(fresh, 1.0)
+    old = [P(0.90)] * 6                                               # six that have run a whole period: 0.6 CPU-s
+    assert not pl._may_start(old, 1.0)
+    pl.spent = collections.deque([(0.95, 0.30)])                      # a finished burst inside the window
+    assert not pl._may_start(fresh, 1.0)
+    assert pl._may_start([P(1.199)] * 6, 1.2) and not pl.spent        # ... forgotten a period later
+    # the parser: cgroup v2 text, "max" = no quota
+    real_open = open
+
+    def fake(text):
+        def _open(path, *a, **k):
+            if str(path) == "/sys/fs/cgroup/cpu.max":
+                import io
+                return io.StringIO(text)
+            return real_open(path, *a, **k)
+        return _open
+
+    import builtins
+    monkeypatch.delenv("PCH_OBB_WORKERS", raising=False)
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    assert obb.cpu_quota() == (16.0, 0.1)
+    assert obb.usable_cpus() == min(16, obb._affinity_cpus())
+    assert obb.default_workers() == min(obb.POOL_CAP, obb._affinity_cpus(), obb.BURST * obb.usable_cpus())
+    monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
+    assert obb.cpu_quota() is None and obb.default_workers() == min(obb.POOL_CAP, obb._affinity_cpus())
+
+
 def test_qhull_is_shown_fewer_points_and_runs_the_same_run():
     """Rows strictly inside qhull's initial simplex are inert in its run; obb.qhull_input leaves them out (natively,
     pch_obbhost_reduce_*).  tools/prefilter_check.py compares hull vertices and candidate directions with the reduction

@@ -33,16 +33,16 @@ p = (rng.normal(size=(43000, 3)) * [2.5, 2.5, 9]).astype(np.float32).astype(np.f
 ConvexHull(p, qhull_options="QbB Pp Qt")
 sys.stdout.write("r\n"); sys.stdout.flush()
 sys.stdin.readline()
-t = time.perf_counter()
+t, c = time.perf_counter(), time.process_time()
 for _ in range(int(sys.argv[2])):
     ConvexHull(p, qhull_options="QbB Pp Qt")
-sys.stdout.write("%f\n" % (time.perf_counter() - t)); sys.stdout.flush()
+sys.stdout.write("%f %f\n" % (time.perf_counter() - t, time.process_time() - c)); sys.stdout.flush()
 """
 
 
 def qhull():
-    for procs in (16, 32, 64, 128):
-        reps = 12
+    for procs in (8, 16, 24, 32, 64):
+        reps = 24
         ps = [subprocess.Popen([sys.executable, "-c", QH, str(i), str(reps)], stdin=subprocess.PIPE,
                                stdout=subprocess.PIPE, text=True) for i in range(procs)]
         for p in ps:
@@ -51,12 +51,14 @@ def qhull():
         for p in ps:
             p.stdin.write("go\n")
             p.stdin.flush()
-        each = [float(p.stdout.readline()) for p in ps]
+        both = [[float(v) for v in p.stdout.readline().split()] for p in ps]
+        each, cpu = [b[0] for b in both], [b[1] for b in both]
         wall = time.perf_counter() - t
         for p in ps:
             p.wait()
         print(f"qhull 43k-point hulls: {procs:4d} processes x {reps}: wall {wall * 1e3:8.1f} ms, "
-              f"{procs * reps / wall:8.1f} hulls/s, per-hull in a process {1e3 * np.mean(each) / reps:6.2f} ms", flush=True)
+              f"{procs * reps / wall:8.1f} hulls/s, per hull in a process {1e3 * np.mean(each) / reps:6.2f} ms wall, "
+              f"{1e3 * np.mean(cpu) / reps:6.2f} ms CPU", flush=True)
 
 
 def _pwrite_all(fd, buf, nthreads, block, base=0):

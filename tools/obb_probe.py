@@ -28,17 +28,13 @@ def timed(label, fn, reps=3):
 
 
 ws = [int(v) for v in os.environ.get("PCH_PROBE_WORKERS", "8,16,24,32,48").split(",")]
-for w in ws:                                   # ascending: the pool only grows
-    os.environ["PCH_OBB_WORKERS"] = str(w)
-    obb.pool(w)
-    time.sleep(1.5)                            # the new workers import scipy
-    tm = {}
-    timed(f"exact, {w} workers", lambda: pipeline.tower_table(cl, timings=tm))
-    print("   split:", {k: (round(v, 2) if isinstance(v, float) else v) for k, v in tm.items()}, flush=True)
-# the stream: tables of tile k beside the device work of tile k+1
-for depth in (1, 2, 3):
+REPS = int(os.environ.get("PCH_PROBE_REPS", "3"))
+
+
+def stream(depth, tiles=6):
+    """tables of tile k beside the device work of tile k+1"""
     jobs, t0 = [], time.perf_counter()
-    for _ in range(6):
+    for _ in range(tiles):
         c2 = pipeline.cluster_points(raw)
         jobs.append(pipeline.tower_table_async(c2))
         del c2
@@ -46,5 +42,16 @@ for depth in (1, 2, 3):
             jobs.pop(0).result()
     while jobs:
         jobs.pop(0).result()
-    print(f"stream, {ws[-1]} workers, {depth} tables in flight: {(time.perf_counter() - t0) / 6 * 1e3:.1f} ms per tile", flush=True)
+    return (time.perf_counter() - t0) / tiles * 1e3
+
+
+for w in ws:                                   # ascending: the pool only grows
+    os.environ["PCH_OBB_WORKERS"] = str(w)
+    obb.pool(w)
+    time.sleep(2.5)                            # the new workers import scipy
+    tm = {}
+    timed(f"exact, {w} workers", lambda: pipeline.tower_table(cl, timings=tm), reps=REPS)
+    print("   split:", {k: (round(v, 2) if isinstance(v, float) else v) for k, v in tm.items()}, flush=True)
+    for depth in (1, 2):
+        print(f"stream, {w} workers, {depth} tables in flight: {stream(depth):.1f} ms per tile", flush=True)
 timed("fast", lambda: pipeline.tower_table(cl, obb_mode="fast"))
