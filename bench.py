@@ -621,14 +621,18 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / k, c2
 
-        # the other workloads of SURVEY 8d on the same harness: the local (zero-offset) frame and the uniform cloud
+        # the other workloads of SURVEY 8d on the same harness: the local (zero-offset) frame and the uniform cloud - and
+        # the worst case of the exact centroid, the corridor centred on itself
         others = {}
-        for kind, frame in (("corridor", "local" if args.frame == "offset" else "offset"), ("uniform", args.frame)):
+        for kind, frame in (("corridor", "local" if args.frame == "offset" else "offset"), ("uniform", args.frame),
+                            ("corridor", "centred")):
             if kind == args.kind and frame == args.frame:
                 continue
             try:
                 tile = synth.corridor_torch(N, seed=seed, kind=kind, offset=(frame == "offset"), device=dev,
                                             dtype=torch.float32)
+                if frame == "centred":      # a cloud normalised to its own centre: zero-mean columns, the float32
+                    tile = tile - tile.double().mean(dim=0).float()   # running sums wander about zero all file long
                 dt2, c2 = timed_steps(tile, 3)
                 others[f"{kind}/{frame}"] = {"ms_per_step": round(dt2 * 1e3, 3), "Mpts_per_s": round(N / dt2 / 1e6, 1),
                                              "filtered_points": int(c2["ground"]["count"]), "clusters": int(c2["nclusters"])}
