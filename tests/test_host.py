@@ -835,6 +835,39 @@ def test_obb_pool_keeps_inside_a_cpu_quota_budget(monkeypatch):
     assert obb.cpu_quota() is None and obb.default_workers() == min(obb.POOL_CAP, obb._affinity_cpus())
 
 
+def test_qhull_is_driven_without_the_wrapper_and_answers_the_same(monkeypatch):
+    """obb._hull_simplices drives scipy's compiled qhull object directly (ConvexHull's own class, same options) and takes
+    only the triangle list: triangles, in qhull's order, must be ConvexHull's on clouds of several shapes and sizes -
+    degenerate input raises the same error - and PCH_OBB_BARE_QHULL=0 (or a failed self-check) goes back to ConvexHull."""
+    from scipy.spatial import ConvexHull
+    from pointcloudhookup_amd import obb
+    rng = np.random.default_rng(77)
+    monkeypatch.setattr(obb, "_BARE", None)
+    monkeypatch.delenv("PCH_OBB_BARE_QHULL", raising=False)
+    shapes = [rng.normal(size=(n, 3)) * sc for n, sc in ((4, [1, 1, 1]), (9, [3, 1, 9]), (500, [2.5, 2.5, 9]),
+                                                         (20000, [3, 2, 11]))]
+    shapes.append(np.round(rng.normal(size=(3000, 3)) * [2, 2, 6], 1))            # many coplanar / duplicate points
+    shapes.append(rng.uniform(-1, 1, size=(2000, 3)) * [10, 10, 0.5] + [437000.0, 3139000.0, 80.0])
+    for c in shapes:
+        c = np.ascontiguousarray(c, dtype=np.float64)
+        want = ConvexHull(c, qhull_options="QbB Pp Qt").simplices
+        got = obb._hull_simplices(c)
+        assert got.dtype == want.dtype and np.array_equal(got, want)
+    assert obb._BARE is True                                                      # the short cut was really taken
+    flat = np.ascontiguousarray(np.c_[rng.normal(size=(50, 2)), np.zeros(50)])    # coplanar: qhull refuses
+    with pytest.raises(Exception) as e1:
+        ConvexHull(flat, qhull_options="QbB Pp Qt")
+    with pytest.raises(Exception) as e2:
+        obb._hull_simplices(flat)
+    assert type(e1.value) is type(e2.value)
+    # switched off: the plain call, same answer
+    monkeypatch.setattr(obb, "_BARE", None)
+    monkeypatch.setenv("PCH_OBB_BARE_QHULL", "0")
+    assert np.array_equal(obb._hull_simplices(shapes[2].astype(np.float64)), ConvexHull(shapes[2], qhull_options="QbB Pp Qt").simplices)
+    assert obb._BARE is False
+    monkeypatch.setattr(obb, "_BARE", None)
+
+
 def test_qhull_is_shown_fewer_points_and_runs_the_same_run():
     """Rows strictly inside qhull's initial simplex are inert in its run; obb.qhull_input leaves them out (natively,
     pch_obbhost_reduce_*).  tools/prefilter_check.py compares hull vertices and candidate directions with the reduction
