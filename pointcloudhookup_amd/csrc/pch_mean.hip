@@ -30,8 +30,10 @@ constexpr int MS_CAND   = 24;
 constexpr int MS_ROW2   = 3 * MS_CAND;      // level-2 row: N0[24], N1[24] (net per incoming parity), A[24]
 constexpr int MS_WAVES  = 4;
 constexpr uint32_t MS_NONFINITE = 1u, MS_ALLZERO = 2u;
+constexpr uint32_t MS_TIGHT = 4u;   // level-1 record: pad[0..3] hold two 64-bit bounds of the running prefix (ms_summary_k)
 constexpr int MS_FIX_FROM = 11;     // sparse-tie fix-up for candidates >= this ...
-constexpr int MS_FIX_MAX  = 8;      // ... holding at most this many tie elements
+constexpr int MS_FIX_LOW  = 6;      // ... and from this one on where the prefix is mostly cancellation (ms_summary_k)
+constexpr int MS_FIX_MAX  = 16;     // ... holding at most this many tie elements
 
 // mask: candidates j whose S / fix entries were computed (bit j); a candidate outside the mask is "unknown" to the walk
 struct MsHdr { int emax; uint32_t tie; uint32_t flags; uint32_t mask; };
@@ -372,6 +374,8 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         // (|S| <= 2^27 per lane) are what is left once the 16 constants are taken off again.
         uint32_t tie = 0;
         int A0 = 0;
+        long long pfx_up = 0, pfx_dn = 0;                      // bounds of the running prefix (24-candidate path)
+        bool have_pfx = false;
         const bool live = !nonfinite && mx != 0;               // wave-uniform
         int S[MS_CAND];
 #pragma unroll
@@ -380,6 +384,7 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         // ---- candidate window (wave-uniform): see the comment above ms_sample_k
         uint32_t cmask = MS_ALLCAND;
         int j0 = 1;                                            // first candidate of the window (>= 1)
+        int fix_from = MS_FIX_FROM;                            // sparse ties are settled for candidates >= this
         if (live && pred) {
             // both signs present?  (-0.0 counts as negative: such a block merely keeps all candidates)
             uint32_t orb = 0;
@@ -395,6 +400,11 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
             const double mass = fabs(pr.pre) + fabs(pr.rowsum);
             // a prefix that is mostly cancellation (|sum| far below the mass that went into it) is not predictable
             const bool cancel = !(fabs(start) * 8.0 >= pr.meanabs * (double)(blk * MSB)) && blk > 0;
+            // the low candidates (a running sum only 2^7 .. 2^11 times the block's largest element) are met where the
+            // prefix is mostly cancellation - a column that wanders about zero; elsewhere their ties (2-16 per block and
+            // candidate, a sweep of the block each) are settled for nothing
+            // (tables built ahead of their walk - no prediction - keep the plain form: config 4's phase 1)
+            if (cancel) fix_from = MS_FIX_LOW;
             if (!mixed && !cancel && mass > 0.0 && pr.meanabs > 0.0) {
                 int E = ms_exp2_floor(start);
                 const int Estag = ms_exp2_floor(pr.meanabs) + 25;       // increments round to zero up there
@@ -446,6 +456,14 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
             for (int j = 1; j < MS_CAND; ++j)
                 acc[j] = 0u - (uint32_t)MS_PER * __float_as_uint((float)(3ull << (22 + j)));
             float absum = 0.0f;
+            // Bounds of the RUNNING prefix sum_{e < k} x_e over the block's elements in file order, k = 0 .. 1024: the
+            // elements i * 64 + l of one i are 64 consecutive ones, so with Cu_i = sum_l ceil(x) and P_i = the positive
+            // part of it, the prefix never exceeds max_i (sum_{i' < i} Cu_i' + P_i) - and never falls below the mirror
+            // image built from the floors.  A0 bounds the prefix by the sum of ALL positive steps whatever their order;
+            // for a column that wanders about zero (both signs in every block) that is ~16 times what the prefix really
+            // reaches, and the walk gives up on blocks it could certify (section 4 of DESIGN.md).
+            long long pre_hi = 0, pre_lo = 0;
+            pfx_up = 0; pfx_dn = 0;
 #pragma unroll
             for (int i = 0; i < MS_PER; ++i) {
                 const float x = ldexpf(a[i], 22 - emax);       // a / ulp(2^(emax+1)), |x| < 2^23, exact
@@ -457,7 +475,19 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
                     const float magic = (float)(3ull << (22 + j));      // 1.5 * 2^(23+j), exact
                     acc[j] += __float_as_uint(x + magic);
                 }
+                if (fix_from == MS_FIX_LOW) {                  // (wave-uniform: where the low candidates matter, see above)
+                    const int cu = (int)ceilf(x);
+                    const auto add = [](uint32_t p, uint32_t q) { return p + q; };
+                    const int Cu = (int)ms_wave_all((uint32_t)cu, add);              // |.| < 2^29
+                    const int P = (int)ms_wave_all((uint32_t)(cu > 0 ? cu : 0), add);
+                    const long long up = pre_hi + P, dn = (long long)(P - Cu + 64) - pre_lo;   // (floor >= ceil - 1)
+                    pfx_up = up > pfx_up ? up : pfx_up;
+                    pfx_dn = dn > pfx_dn ? dn : pfx_dn;
+                    pre_hi += Cu;
+                    pre_lo += Cu - 64;
+                }
             }
+            have_pfx = fix_from == MS_FIX_LOW;
 #pragma unroll
             for (int j = 0; j < MS_CAND; ++j) S[j] = (int)acc[j];
             // A0 only has to be an upper bound of sum |x|: the float32 sum of 16 terms is low by at most
@@ -472,7 +502,7 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         // v of every tie element; a tie met at odd parity takes the other neighbour, v +- 1).
         uint32_t myfix = 0;                                    // lane j keeps (adj0 & 0xFFFF) | adj1 << 16
         {
-            uint32_t todo = tie & ~((1u << MS_FIX_FROM) - 1u);
+            uint32_t todo = tie & ~((1u << fix_from) - 1u);
             while (todo) {
                 const int j = __ffs((int)todo) - 1;
                 todo &= todo - 1;
@@ -570,13 +600,18 @@ __global__ __launch_bounds__(64 * MS_WAVES) void ms_summary_k(const float* __res
         }
         }
         if (l < MS_CAND) rec->fix[l] = myfix;
-        if (l < 18) rec->pad[l] = 0;
+        if (l >= 4 && l < 18) rec->pad[l] = 0;
         if (l == 0) {
+            rec->pad[0] = 0; rec->pad[1] = 0; rec->pad[2] = 0; rec->pad[3] = 0;
             rec->A0 = A0w;
             rec->h.emax = emax;
             rec->h.tie = tie;
-            rec->h.flags = (nonfinite ? MS_NONFINITE : 0u) | (mx == 0 ? MS_ALLZERO : 0u);
+            rec->h.flags = (nonfinite ? MS_NONFINITE : 0u) | (mx == 0 ? MS_ALLZERO : 0u) | (have_pfx ? MS_TIGHT : 0u);
             rec->h.mask = cmask;
+            if (have_pfx) {                                    // (up to 2^33 each: two words)
+                rec->pad[0] = (uint32_t)pfx_up; rec->pad[1] = (uint32_t)((unsigned long long)pfx_up >> 32);
+                rec->pad[2] = (uint32_t)pfx_dn; rec->pad[3] = (uint32_t)((unsigned long long)pfx_dn >> 32);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (l < 24)                                            // 24 x 16 bytes: three full lines
@@ -856,6 +891,17 @@ __device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ x
             const uint32_t f = rec->fix[j];
             en = ms_entry(S + (long long)(short)(f & 0xFFFFu), S + (long long)(short)(f >> 16),
                           (rec->A0 >> j) + MSB, s_neg);
+            if (h.flags & MS_TIGHT) {
+                // the record also bounds the running prefix in file order (ms_summary_k): a step differs from x / 2^j by
+                // at most 1/2 (a tie taken the other way included), so k steps stay within k / 2 <= 512 of the prefix of x
+                const long long pu = (long long)(((unsigned long long)rec->pad[1] << 32) | rec->pad[0]);
+                const long long pd = (long long)(((unsigned long long)rec->pad[3] << 32) | rec->pad[2]);
+                const long long up = ((pu + ((1ll << j) - 1)) >> j) + MSB / 2 + MS_FIX_MAX;
+                const long long dn = ((pd + ((1ll << j) - 1)) >> j) + MSB / 2 + MS_FIX_MAX;
+                const long long hi = s_neg ? dn : up, lo = -(s_neg ? up : dn);
+                en.hi = hi < en.hi ? hi : en.hi;
+                en.lo = lo > en.lo ? lo : en.lo;
+            }
         }
         int start = done;                               // first unresolved lane
         long long m_cur = (long long)((sb & 0x7FFFFFu) | 0x800000u);   // mantissa entering `start`

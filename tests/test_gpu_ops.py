@@ -199,6 +199,29 @@ def test_mean_seq_hard_stretches_and_ragged_end(cuda):
     np.testing.assert_array_equal(flt["index"].cpu().numpy(), np.flatnonzero(ref["keep"]))
 
 
+def test_mean_seq_clouds_centred_on_themselves(cuda):
+    """Zero-mean columns: the running sums wander about zero for the whole file, every block holds both signs, and the
+    walk leans on the level-1 records' bounds of the RUNNING prefix (ms_summary_k, MS_TIGHT) instead of the order-free
+    sum of the positive steps.  A corridor minus its own centroid; and columns whose blocks carry prefix bounds beyond
+    32 bits (long same-sign plateaus of large values that cancel later, then noise of the same size) - a bound cut to
+    32 bits and then scaled to a high candidate binade once certified blocks it must not."""
+    from pointcloudhookup_amd import synth
+    pts = synth.corridor_numpy(6_000_000, seed=synth.SEED0 + 9, kind="corridor", offset=False)
+    raw = (pts - pts.mean(axis=0)).astype(np.float32)
+    got = ops.mean_seq_f32(_dev(raw, cuda)).cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.uint32), np.mean(raw, axis=0).view(np.uint32))
+    rng = np.random.default_rng(2026)
+    n = 4_200_000
+    a = np.concatenate([np.full(1_400_000, 3.1e6), np.full(1_400_000, -3.1e6), rng.normal(0, 1.0e6, 1_400_000)])
+    b = np.concatenate([rng.normal(0, 2.0e6, 1_400_000), np.full(1_400_000, 7.7e5), rng.normal(-7.7e5, 3.0e5, 1_400_000)])
+    c = rng.uniform(-50.0, 50.0, n) + np.where(np.arange(n) % 200_000 < 100_000, 2.2, -2.2)
+    raw = np.column_stack([a, b, c]).astype(np.float32)
+    got = ops.mean_seq_f32(_dev(raw, cuda)).cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.uint32), np.mean(raw, axis=0).view(np.uint32))
+    ser = ops.mean_seq_f32(_dev(raw, cuda), serial=True).cpu().numpy()
+    np.testing.assert_array_equal(ser.view(np.uint32), got.view(np.uint32))
+
+
 def _chained(raw, cuts, cuda):
     """np.mean over shards chained in file order: running sums handed from shard to shard, the last one divides"""
     run = None
