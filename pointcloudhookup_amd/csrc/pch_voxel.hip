@@ -220,12 +220,15 @@ __global__ __launch_bounds__(VP_MAXBINS) void vx_binscan_k(VoxelPlan g, uint32_t
                                                            VoxelOversize* __restrict__ over,
                                                            uint32_t* __restrict__ nover) {
     __shared__ uint32_t wsum[VP_MAXBINS / 64];
-    __shared__ uint32_t ucount[VP_MAXBINS], ustart[VP_MAXBINS];
+    __shared__ __attribute__((aligned(16))) uint32_t ucount[VP_MAXBINS];
+    __shared__ uint32_t ustart[VP_MAXBINS];
     const int64_t c = blockIdx.x;
     const int b = threadIdx.x;
     uint32_t run = 0;
     if (b < g.nb) {
-        constexpr int U = 8;                               // loads of eight tiles in flight
+        constexpr int U = 32;                              // loads of 32 tiles in flight (a chunk of 500 000 rows has 123:
+                                                           // four round trips instead of sixteen - the kernel is one
+                                                           // workgroup per chunk and nothing but these round trips)
         for (int64_t t0 = 0; t0 < g.tiles_per_chunk; t0 += U) {
             uint32_t h[U];
 #pragma unroll
@@ -248,6 +251,8 @@ __global__ __launch_bounds__(VP_MAXBINS) void vx_binscan_k(VoxelPlan g, uint32_t
         unit_start[c * g.nb + b] = st;
         ucount[b] = run;
         ustart[b] = st;
+    } else {
+        ucount[b] = 0;                                     // (the grouping below reads the counts four at a time)
     }
     const uint32_t nonempty = (uint32_t)__syncthreads_count(b < g.nb && run != 0);
     if (b == 0) {                                          // greedy grouping, in digit order
@@ -263,8 +268,16 @@ __global__ __launch_bounds__(VP_MAXBINS) void vx_binscan_k(VoxelPlan g, uint32_t
         // a batch covers the digits [first, last] of its first and last NON-EMPTY unit (empty units in between
         // cost nothing but would widen the sort key)
         uint32_t last = 0, seen = 0;
-        for (uint32_t d = 0; d < (uint32_t)g.nb; ++d) {
-            const uint32_t cnt = ucount[d];
+        // (one thread, in digit order: the counts come four per LDS read - one dependent read per digit was most of
+        // this kernel's 70 us, which every call waits for whatever its size)
+        for (uint32_t d4 = 0; d4 < (uint32_t)g.nb; d4 += 4) {
+          const uint4 c4 = *reinterpret_cast<const uint4*>(&ucount[d4]);
+          const uint32_t cq[4] = {c4.x, c4.y, c4.z, c4.w};
+          if ((c4.x | c4.y | c4.z | c4.w) == 0u) continue;
+#pragma unroll
+          for (uint32_t dd = 0; dd < 4; ++dd) {
+            const uint32_t d = d4 + dd;
+            const uint32_t cnt = cq[dd];
             if (cnt == 0) continue;
             ++seen;
             if (rows && (rows + cnt > (uint32_t)VF_CAP || d - first >= maxdig)) {   // close the open batch
@@ -292,6 +305,7 @@ __global__ __launch_bounds__(VP_MAXBINS) void vx_binscan_k(VoxelPlan g, uint32_t
                 }
                 rows = 0;
             }
+          }
         }
         if (rows) emit(ustart[first], rows, first, last - first + 1);
         nbatch[c] = nbt;
