@@ -640,64 +640,176 @@ __device__ __forceinline__ void ms_scan_pairs(long long& c0, long long& c1) {
     }
 }
 
-constexpr int MS_SEG = 16;                       // consecutive elements per lane in ms_blocks_exact
+#ifdef PCH_MS_STAMPS                              // tuning build: shader-clock time per phase of ms_blocks_exact (z column) into stats[27..31]
+__device__ unsigned long long ms_stamp_acc[8];
+#define MS_STAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); \
+                         if (threadIdx.x == 0 && c == 2) ms_stamp_acc[(i)] += t_ - ms_t_; ms_t_ = t_; } while (0)
+#define MS_STAMP_DECL unsigned long long ms_t_ = __builtin_readcyclecounter()
+#else
+#define MS_STAMP(i) do { } while (0)
+#define MS_STAMP_DECL do { } while (0)
+#endif
+constexpr int MS_SEG = 16;                       // consecutive elements per lane in the serial chain of ms_blocks_exact
+constexpr int MS_XW = 4;                         // waves of the walk's workgroup (they all run the same walk and share the
+                                                 // work only inside ms_blocks_exact)
+constexpr int MS_XPART = MSB / MS_XW;            // elements of a block per wave there
 __device__ __forceinline__ int ms_pad(int i) { return i + (i >> 4); }   // LDS bank spreading
 
-// Adds the level-1 blocks [blk, blk + nblk) to the running sum exactly: literally the sequential float32 chain, run
-// out of registers.  Lane l holds the 16 consecutive elements [16 l, 16 l + 16) of a block (staged through LDS so that
-// the global loads stay coalesced); in round r EVERY lane chains its 16 elements onto the (wave-uniform) running sum
-// and lane r's result becomes the running sum of round r + 1 (v_readlane).  64 rounds x 17 dependent instructions
-// ~ 2.3 us per block, whatever the data; the rows of the NEXT block of a run are requested before the chain of this one
-// starts.  (The earlier form - certified parallel passes at the current binade + element-by-element stretches read back
-// from LDS - cost 2.4 us per PASS and 10 ns per serial element: 3-11 us per block.)  Rows beyond the array's end count
-// as -0.0: s + (-0.0) = s for every s, -0.0 included.  NaN and inf propagate as in numpy's own chain.
+struct alignas(16) MsExact {                     // LDS of the exact path
+    float    plain[MSB];                         // the block in file order (uniform reads of the candidate chains)
+    float    padded[MSB + MSB / 16];             // the same, bank-spread: lane l reads its 16 consecutive elements
+    double   psum[MS_XW];                        // real sum of every wave's part (float64)
+    uint32_t tab[MS_XW][64];                     // the part's chain run from 64 neighbouring start values
+};
+
+// floats as integers in their own order (-0.0 -> -1, +0.0 -> 0): the neighbours of a float are key +- 1
+__device__ __forceinline__ int ms_key(uint32_t b) { return (int)(b ^ (uint32_t)(((int)b >> 31) & 0x7FFFFFFF)); }
+__device__ __forceinline__ uint32_t ms_unkey(int k) { return (uint32_t)k ^ (uint32_t)((k >> 31) & 0x7FFFFFFF); }
+
+__device__ __forceinline__ double ms_wave_sum_f64(double v) {           // every lane gets the wave's sum (fixed order)
+    auto halves = [](double d, uint32_t& lo, uint32_t& hi) {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(d);
+        lo = (uint32_t)u; hi = (uint32_t)(u >> 32);
+    };
+    auto whole = [](uint32_t lo, uint32_t hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); };
+    uint32_t lo, hi;
+#define MS_F64_ROR(CTRL) halves(v, lo, hi); v = v + whole(ms_dpp<CTRL>(lo), ms_dpp<CTRL>(hi))
+    MS_F64_ROR(MS_ROR8); MS_F64_ROR(MS_ROR4); MS_F64_ROR(MS_ROR2); MS_F64_ROR(MS_ROR1);
+#undef MS_F64_ROR
+    halves(v, lo, hi);
+    const auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = whole(l16[0], h16[0]) + whole(l16[1], h16[1]);
+    halves(v, lo, hi);
+    const auto l32 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto h32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return whole(l32[0], h32[0]) + whole(l32[1], h32[1]);
+}
+
+// Adds the level-1 blocks [blk, blk + nblk) to the running sum exactly.
+// The reference is the sequential float32 chain itself: lane l holds the 16 consecutive elements [16 l, 16 l + 16) of a
+// block, in round r every lane chains its 16 elements onto the (wave-uniform) running sum and lane r's result becomes the
+// running sum of round r + 1 (v_readlane) - 64 rounds x 17 dependent instructions ~ 3.4 us per block whatever the data:
+// a lone wave issues a dependent add every ~8 cycles, and that IS the floor of a sequential float32 sum on one wave.
+// Round 4: FOUR waves, each with a quarter of the block, and 64 start values per wave.  A chain depends on its start
+// value only; wave w does not know the sum that will enter its quarter, but it knows it to a few ulps - the incoming sum
+// plus the REAL sum of the quarters in front (float64) is off by the roundings of at most 768 additions, ~8 ulps rms - so
+// lane l of wave w runs the quarter's 256-step chain from the float (l - 32) neighbours away from that estimate: 64
+// literal chains at the price of one (every lane of a wave computes anyway).  Wave 0's estimate IS the incoming sum;
+// its result is looked up among wave 1's start values, that result among wave 2's, and so on: three table reads
+// instead of 768 dependent additions.  Nothing is approximated: a result is taken from a chain that started at exactly
+// the value that arrived (same bits), or not at all - a start value outside its window (a sum that dropped by binades
+// inside the block: its ulps shrank under the estimate's error) sends the rest of the block to the serial chain, from
+// the last quarter that was resolved.  Non-finite sums or elements take the serial chain outright (NaN and inf
+// propagate as in numpy's own loop).  Rows beyond the array's end count as -0.0: s + (-0.0) = s for every s, -0.0
+// included.  All four waves run the same walk on the same data (the tables are read-only), so they arrive here
+// together.
 // first_decides: stop behind the first block if the sum is still in the binade (and has the sign) it came with - the
 // caller's tables are still valid then; `added` returns the number of blocks that were added.
 __device__ __forceinline__ uint32_t ms_blocks_exact(const float* __restrict__ xyz, int64_t n, int c,
-                                                    int64_t blk, int nblk, uint32_t sb, float* stage, int* dbg,
+                                                    int64_t blk, int nblk, uint32_t sb, MsExact* X, int* dbg,
                                                     bool first_decides, int& added) {
-    const int l = lane_id();
-    float v0[MSB / 64], v1[MSB / 64];                    // coalesced loads of the next two blocks (two chains of time
-                                                         // for every load to arrive)
-    auto fetch = [&](int64_t b, float (&v)[MSB / 64]) {
-        const int64_t p0 = b * MSB;
+    const int l = lane_id(), w = wave_id();
+    constexpr int PER = MS_XPART / 64;                   // elements per lane of a wave's part (coalesced)
+    float v0[PER], v1[PER], v2[PER];                     // this wave's part of the next three blocks
+    auto fetch = [&](int64_t b, float (&v)[PER]) {
+        const int64_t p0 = b * MSB + w * MS_XPART;
 #pragma unroll
-        for (int k = 0; k < MSB / 64; ++k) {
+        for (int k = 0; k < PER; ++k) {
             const int64_t i = p0 + l + 64 * k;
             v[k] = i < n ? xyz[3 * i + c] : -0.0f;
         }
     };
     fetch(blk, v0);
     if (nblk > 1) fetch(blk + 1, v1);
+    if (nblk > 2) fetch(blk + 2, v2);
     float s = __uint_as_float(sb);
     added = 0;
+    MS_STAMP_DECL;
     for (int q = 0; q < nblk; ++q) {
+        MS_STAMP(0);
+        double mine = 0.0;
 #pragma unroll
-        for (int k = 0; k < MSB / 64; ++k) stage[ms_pad(l + 64 * k)] = v0[k];
+        for (int k = 0; k < PER; ++k) {
+            const int e = w * MS_XPART + l + 64 * k;
+            X->plain[e] = v0[k];
+            X->padded[ms_pad(e)] = v0[k];
+            mine += (double)v0[k];
+        }
+        mine = ms_wave_sum_f64(mine);
+        if (l == 0) X->psum[w] = mine;
         __syncthreads();
-        float a[MS_SEG];
 #pragma unroll
-        for (int k = 0; k < MS_SEG; ++k) a[k] = stage[ms_pad(MS_SEG * l + k)];
-        __syncthreads();                                 // the stage may be overwritten by the next block
-#pragma unroll
-        for (int k = 0; k < MSB / 64; ++k) v0[k] = v1[k];
-        if (q + 2 < nblk) fetch(blk + q + 2, v1);        // in flight during this chain and the next
+        for (int k = 0; k < PER; ++k) { v0[k] = v1[k]; v1[k] = v2[k]; }
+        if (q + 3 < nblk) fetch(blk + q + 3, v2);        // in flight during this block and the next two
         const int64_t left = n - (blk + q) * MSB;
         const int cnt = (int)(left < MSB ? left : MSB);
-        auto round = [&](int r) {
-            float t = s;
+        const int rounds = (cnt + MS_SEG - 1) / MS_SEG;
+        int r0 = 0;                                      // first round the serial chain still has to do
+        double tot = 0.0;
 #pragma unroll
-            for (int k = 0; k < MS_SEG; ++k) t = t + a[k];
-            s = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(t), r));
-        };
-        if (cnt == MSB) {                                // (a constant trip count: the loop bookkeeping of 64 short
-#pragma unroll 8                                         //  rounds is a sixth of the chain otherwise)
-            for (int r = 0; r < MSB / MS_SEG; ++r) round(r);
-        } else {
-            const int rounds = (cnt + MS_SEG - 1) / MS_SEG;
-            for (int r = 0; r < rounds; ++r) round(r);
+        for (int k = 0; k < MS_XW; ++k) tot += X->psum[k];
+        const uint32_t sbits = __float_as_uint(s);
+        MS_STAMP(1);                                     // 0 -> 1: rows arrived, staged, summed
+        if (((sbits >> 23) & 0xFFu) != 255u && fabs(tot) < INFINITY) {     // finite sum, finite elements
+            double pre = 0.0;
+            for (int k = 0; k < w; ++k) pre += X->psum[k];
+            const int kc = ms_key(__float_as_uint((float)((double)s + pre)));
+            float v = __uint_as_float(ms_unkey(kc + (l - 32)));
+            // the part's elements in file order: uniform 16-byte LDS reads, 64 elements requested ahead of the adds that
+            // use them (a read in front of every dependent add would cost more than the add)
+            const float4* p4 = reinterpret_cast<const float4*>(X->plain + w * MS_XPART);
+            constexpr int G = 16;                            // float4 per stage
+            float4 ea[G], eb[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) ea[i] = p4[i];
+#pragma unroll
+            for (int g = 0; g < MS_XPART / 4 / G; g += 2) {
+#pragma unroll
+                for (int i = 0; i < G; ++i) eb[i] = p4[(g + 1) * G + i];
+#pragma unroll
+                for (int i = 0; i < G; ++i) { v = v + ea[i].x; v = v + ea[i].y; v = v + ea[i].z; v = v + ea[i].w; }
+                if (g + 2 < MS_XPART / 4 / G) {
+#pragma unroll
+                    for (int i = 0; i < G; ++i) ea[i] = p4[(g + 2) * G + i];
+                }
+#pragma unroll
+                for (int i = 0; i < G; ++i) { v = v + eb[i].x; v = v + eb[i].y; v = v + eb[i].z; v = v + eb[i].w; }
+            }
+            X->tab[w][l] = __float_as_uint(v);
+            MS_STAMP(2);                                 // 1 -> 2: the 64 chains
+            __syncthreads();
+            uint32_t rb = X->tab[0][32];                 // wave 0 started lane 32 at the incoming sum itself
+            int done = 1;                                // parts resolved
+            pre = X->psum[0];
+            for (int k = 1; k < MS_XW; ++k) {
+                const int kk = ms_key(__float_as_uint((float)((double)s + pre)));
+                const long long idx = (long long)ms_key(rb) - kk + 32;
+                if (idx < 0 || idx >= 64) break;
+                rb = X->tab[k][(int)idx];
+                pre += X->psum[k];
+                ++done;
+            }
+            s = __uint_as_float(rb);
+            r0 = done * (MS_XPART / MS_SEG);
+            if (dbg) dbg[0] += done;                     // quarters taken from the tables
+            MS_STAMP(3);                                 // 2 -> 3: look-ups
         }
-        if (dbg) { dbg[1] += cnt; ++dbg[2]; }            // elements added one by one / blocks
+        if (r0 < rounds) {                               // the serial chain for what is left (all of it: non-finite input)
+            float a[MS_SEG];
+#pragma unroll
+            for (int k = 0; k < MS_SEG; ++k) a[k] = X->padded[ms_pad(MS_SEG * l + k)];
+            for (int r = r0; r < rounds; ++r) {
+                float t = s;
+#pragma unroll
+                for (int k = 0; k < MS_SEG; ++k) t = t + a[k];
+                s = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(t), r));
+            }
+            if (dbg) dbg[1] += (rounds - r0) * MS_SEG;   // elements added one by one
+        }
+        if (dbg) ++dbg[2];                               // blocks
+        __syncthreads();                                 // the stage is overwritten by the next block
+        MS_STAMP(4);                                     // 3 -> 4: serial rest + barrier
         ++added;
         if (q == 0 && first_decides) {
             const uint32_t ef = (sb >> 23) & 0xFFu;
@@ -865,7 +977,7 @@ __device__ __forceinline__ int ms_certify(int cls, const MsEntry& e, bool valid,
 // Adds the level-1 blocks [first, first+count), count <= 64, to the running sum `sb` (bits).
 __device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ xyz, int64_t n, int c,
                                                      const MsTables& T, int64_t first, int count,
-                                                     uint32_t sb, float* stage, int& n_exact, int& streak,
+                                                     uint32_t sb, MsExact* stage, int& n_exact, int& streak,
                                                      int& n_miss, int* dbg) {
     const int l = lane_id();
     int done = 0;                                       // children already added
@@ -943,10 +1055,11 @@ __device__ __forceinline__ uint32_t ms_walk_children(const float* __restrict__ x
 // its certificate fails
 // sum_in (optional): the running sum this shard continues (a file-order shard of a larger array, see
 // pch_mean_seq_partial_f32); divide_n: 0 = store the running sum itself, else divide by float32(divide_n)
-__global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, int64_t n, MsTables T,
+__global__ __launch_bounds__(64 * MS_XW) void ms_walk_k(const float* __restrict__ xyz, int64_t n, MsTables T,
                                                 const float* __restrict__ sum_in, int64_t divide_n, int divide,
                                                 float* __restrict__ out, int* __restrict__ stats) {
-    __shared__ float stage[MSB + MSB / 16];
+    __shared__ MsExact stage_x;
+    MsExact* stage = &stage_x;
     const int c = blockIdx.x;
     const int l = lane_id();
     uint32_t sb = sum_in ? __float_as_uint(sum_in[c]) : 0u;      // bits of the running sum (+0.0 at the start)
@@ -994,13 +1107,16 @@ __global__ __launch_bounds__(64) void ms_walk_k(const float* __restrict__ xyz, i
         }
         b += reload ? start : 64;
     }
-    if (l == 0) {
+    if (threadIdx.x == 0) {
         // n == 0 -> 0/0 = NaN like numpy
         out[c] = divide ? __uint_as_float(sb) / (float)divide_n : __uint_as_float(sb);
         if (stats) {
             stats[4 * c + 0] = n_batches; stats[4 * c + 1] = n_miss;     // n_miss: exact blocks the window caused
             stats[4 * c + 2] = n_exact; stats[4 * c + 3] = n_desc;
             stats[16 + 4 * c + 0] = dbg[0]; stats[16 + 4 * c + 1] = dbg[1]; stats[16 + 4 * c + 2] = dbg[2];
+#ifdef PCH_MS_STAMPS
+            if (c == 2) for (int i = 0; i < 5; ++i) { stats[27 + i] = (int)(ms_stamp_acc[i] >> 6); ms_stamp_acc[i] = 0; }
+#endif
         }
     }
 }
@@ -1084,7 +1200,7 @@ int mean_seq_launch(const float* xyz, int64_t n, float* out, MsWs& w, float* zco
     T.rec = w.rec; T.nb = nb;
     T.hdr2 = w.hdr2; T.rows2 = w.rows2; T.nb2 = nb2;
     const int divide = divide_n != MS_NO_DIVIDE;
-    PCH_LAUNCH("mean_walk", ms_walk_k, dim3(3), dim3(64), 0, ws, xyz, n, T, sum_in,
+    PCH_LAUNCH("mean_walk", ms_walk_k, dim3(3), dim3(64 * MS_XW), 0, ws, xyz, n, T, sum_in,
                divide_n == MS_DIVIDE_BY_N ? n : divide_n, divide, out, w.stats);
     return PCH_OK;
 }

@@ -26,7 +26,7 @@ for kind, offset in (("corridor", True), ("corridor", False), ("uniform", True),
     raw_st = ws[:128].view(torch.int32).cpu().numpy()
     st = raw_st[:16].reshape(4, 4)[:3]
     ex = raw_st[16:28].reshape(3, 4)
-    stamps = raw_st[27:31]                          # tuning build (-DPCH_MS_STAMPS): y column, shader cycles / 64
+    stamps = raw_st[27:32]                          # tuning build (-DPCH_MS_STAMPS): y column, shader cycles / 64
     ops.set_profiling(True)
     ops.mean_seq_f32(x)
     torch.cuda.synchronize()
@@ -34,7 +34,8 @@ for kind, offset in (("corridor", True), ("corridor", False), ("uniform", True),
     ops.set_profiling(False)
     print(f"{kind}, frame {'offset' if offset is True else offset or 'local'}: {dt:.2f} ms, mean {out.cpu().numpy()}  kernels {prof}")
     if stamps.any():
-        print("  y column, ms_blocks_exact phases (shader cycles x 64): stage", stamps[1], "passes", stamps[2], "chain", stamps[3])
+        print("  z column, ms_blocks_exact phases (shader cycles / 64): between blocks", raw_st[27], "stage", raw_st[28], "chains",
+              raw_st[29], "look-ups", raw_st[30], "serial rest", raw_st[31])
     for c, name in enumerate("xyz"):
         print(f"  column {name}: batches {st[c, 0]}, exact blocks {st[c, 2]} (of them {st[c, 1]} because the candidate "
               f"window missed), descents {st[c, 3]}; exact path: {ex[c, 2]} calls, {ex[c, 0]} passes, "
