@@ -15,10 +15,11 @@
 //                  sum|d_i| <= (A0 >> j) + 1024) and a tie bit per candidate (an element ties at
 //                  exactly one candidate: the one just above its lowest set bit).
 //   ms_level2_k  : rows for 64 blocks (65 536 points): child rows added at equal absolute binade.
-//   ms_walk_k    : one wave per column walks level-2 rows 64 at a time (prefix scan of the
+//   ms_walk_k    : one workgroup per column walks level-2 rows 64 at a time (prefix scan of the
 //                  increments + per-row certificate that no prefix can leave the binade), opens
-//                  the children of a row that fails, and adds a child that fails exactly with all
-//                  64 lanes (ms_blocks_exact).
+//                  the children of a row that fails, and adds a child that fails exactly: its four
+//                  waves (which all run the same walk) chain a quarter of the block each, from 64
+//                  neighbouring start values, and the quarters are joined by look-ups (ms_blocks_exact).
 // Order inside a certified block is irrelevant, hence the result equals the sequential sum.
 #include "pch_mean.h"
 
