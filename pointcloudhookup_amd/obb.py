@@ -446,6 +446,8 @@ def usable_cpus():
 
 POOL_CAP = 64         # worker processes at most (a 100 M-point tile has ~230 clusters; beyond ~4 per worker the tail idles)
 BURST = 2             # under a CPU quota: worker processes per quota core (see Pool._may_start)
+import os as _os
+LEDGER = float(_os.environ.get("PCH_OBB_LEDGER", "0.8"))   # share of a period's CPU budget the pool lets itself spend
 
 
 def default_workers():
@@ -675,7 +677,7 @@ class Pool:
         while self.spent and self.spent[0][0] < now - period:
             self.spent.popleft()
         used = sum(c for _, c in self.spent) + sum(min(now - p.t_task, period) for p in busy)
-        return used + 0.004 * (len(busy) + 1) < 0.8 * cores * period
+        return used + 0.004 * (len(busy) + 1) < LEDGER * cores * period
 
     def _hand_out(self, sel, procs):
         """queued tasks to idle, ready workers; returns True when tasks are left over only for want of budget"""
