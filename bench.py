@@ -478,21 +478,27 @@ def main():
     knn_bytes_all, knn_bytes, occ = knn_tile_bytes(cl["ground"]["points"], EPS, CHUNK, MIN_POINTS)
     dom = kernels[0]
 
-    def roof(name, avg_ms):
+    def roof(name, avg_ms, per_step=1.0):
+        # a kernel that is launched several times per step over consecutive parts of the tile (mean_summary in slices):
+        # algorithmic bytes per LAUNCH = the step's bytes / launches per step, against the average launch duration
         if name in ("db_core", "db_union", "db_border"):
             b = knn_bytes
         else:
             b = algorithmic_bytes(name, N, NF)
         if b is None or avg_ms <= 0:
             return None
+        b = b / max(per_step, 1.0)
         a = b / (avg_ms * 1e-3) / 1e9
-        return dict(kernel=name, bound="hbm", achieved=round(a, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(a / HBM_PEAK_GBS, 4), traffic=None, avg_ms=round(avg_ms, 4),
-                    bytes_per_launch=int(b))
+        r = dict(kernel=name, bound="hbm", achieved=round(a, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                 frac=round(a / HBM_PEAK_GBS, 4), traffic=None, avg_ms=round(avg_ms, 4),
+                 bytes_per_launch=int(b))
+        if per_step > 1.0:
+            r["launches_per_step"] = per_step
+        return r
 
-    roofline = roof(dom[0], dom[1]) or dict(kernel=dom[0], bound="hbm", achieved=None,
-                                            peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None)
-    knn = next((roof(r[0], r[1]) for r in kernels if r[0] == "db_core"), None)
+    roofline = roof(dom[0], dom[1], dom[2] / args.steps) or dict(kernel=dom[0], bound="hbm", achieved=None,
+                                                                 peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None)
+    knn = next((roof(r[0], r[1], r[2] / args.steps) for r in kernels if r[0] == "db_core"), None)
     if knn:
         # The radius kernel is not bound by HBM: its figure of merit is
         # pair tests per second.  The byte MODELS of SURVEY 8(d) stay in the line, after the counter-based figures,
@@ -538,7 +544,7 @@ def main():
     if roofline.get("kernel") == "mean_walk":
         roofline["note"] = ("largest kernel by time is the exact-centroid walk: a serial dependency chain on "
                             "3 wavefronts (latency-bound); see streaming_kernel for the largest HBM-bound kernel")
-    stream = next((roof(r[0], r[1]) for r in kernels
+    stream = next((roof(r[0], r[1], r[2] / args.steps) for r in kernels
                    if r[0] not in ("mean_walk", "db_core", "db_union0", "db_union1", "db_border")
                    and algorithmic_bytes(r[0], N, NF)), None)
     tr_path = os.path.join(ROOT, "profiles", "traffic.json")   # PMC passes, see profiles/README.md
