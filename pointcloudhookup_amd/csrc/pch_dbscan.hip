@@ -22,6 +22,8 @@ constexpr int DB_WAVES   = DB_THREADS / 64;
 constexpr int DB_ROWS    = 25;
 constexpr int INT_BIG    = 0x7fffffff;
 constexpr int DB_FEW_QUERIES = 24;
+constexpr int DB_AHEAD = 3;              // db_core_k, long sweeps: 64-candidate groups whose loads are in flight together
+constexpr long long DB_LONG_TOT = 8192;  // ... a cell counts as long from this many candidates in its neighbourhood
 constexpr int DB_SEGS = 43;          // 9 inner + 9 + 9 end pieces of the near runs + 16 outer runs
 
 struct DbGrid {
@@ -837,20 +839,46 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
         __builtin_amdgcn_wave_barrier();
     }
     uint32_t ncore = 0;
+    const bool long_sweep = tot >= DB_LONG_TOT;            // wave-uniform
     if (cnt < DB_FEW_QUERIES) {
         // a handful of queries (cluster fringe): lanes sweep the candidates of one query at a
         // time and leave at min_samples - usually within the first tile of a dense neighbour
         for (uint32_t q = s; q < e; ++q) {
             const float4 qp = pts[q];
             int count = 0;
-            for (int r = 0; r < DB_SEGS && count < g.min_samples; ++r) {
-                const uint32_t pa = sa[r], pb = sb[r];
-                for (uint32_t j0 = pa; j0 < pb && count < g.min_samples; j0 += 64) {
-                    const uint32_t j = j0 + l;
-                    bool hit = false;
-                    if (j < pb) hit = db_within2(qp, pts[j], g);
-                    count += (int)__popcll(__ballot(hit));
-                    if (COUNT) { n_useful += (pb - j0) < 64u ? (pb - j0) : 64u; n_slots += 64; }
+            if (long_sweep) {
+                // A lone point beside a tower core that is NOT core passes every candidate of its neighbourhood (13 585
+                // in the bench tile) - one dependent load per 64 candidates made such a wave the tail of the kernel.
+                // Where the neighbourhood is that large, DB_AHEAD groups per trip, their loads in flight together (the
+                // same candidates in the same order; a sweep leaves at min_samples either way).
+                for (int r = 0; r < DB_SEGS && count < g.min_samples; ++r) {
+                    const uint32_t pa = sa[r], pb = sb[r];
+                    for (uint32_t j0 = pa; j0 < pb && count < g.min_samples; j0 += 64u * DB_AHEAD) {
+                        float4 P[DB_AHEAD];
+#pragma unroll
+                        for (int u = 0; u < DB_AHEAD; ++u) {
+                            const uint32_t j = j0 + 64u * u + l;
+                            P[u] = pts[j < pb ? j : pb - 1];
+                        }
+#pragma unroll
+                        for (int u = 0; u < DB_AHEAD; ++u) {
+                            const uint32_t jb = j0 + 64u * u;
+                            const bool hit = jb + l < pb && db_within2(qp, P[u], g);
+                            count += (int)__popcll(__ballot(hit));
+                            if (COUNT && jb < pb) { n_useful += (pb - jb) < 64u ? (pb - jb) : 64u; n_slots += 64; }
+                        }
+                    }
+                }
+            } else {
+                for (int r = 0; r < DB_SEGS && count < g.min_samples; ++r) {
+                    const uint32_t pa = sa[r], pb = sb[r];
+                    for (uint32_t j0 = pa; j0 < pb && count < g.min_samples; j0 += 64) {
+                        const uint32_t j = j0 + l;
+                        bool hit = false;
+                        if (j < pb) hit = db_within2(qp, pts[j], g);
+                        count += (int)__popcll(__ballot(hit));
+                        if (COUNT) { n_useful += (pb - j0) < 64u ? (pb - j0) : 64u; n_slots += 64; }
+                    }
                 }
             }
             const bool is_core = count >= g.min_samples;
@@ -901,15 +929,36 @@ __global__ __launch_bounds__(DB_THREADS) void db_core_k(DbGrid g, const float4* 
             int cq = __shfl(count, ql, 64);
             int rr = r;
             uint32_t jj = j0;
-            while (rr < DB_SEGS && cq < g.min_samples) {
-                const uint32_t pb = sb[rr];
-                if (jj >= pb) { ++rr; if (rr < DB_SEGS) jj = sa[rr]; continue; }
-                const uint32_t j = jj + l;
-                bool hit = false;
-                if (j < pb) hit = db_within2(qp, pts[j], g);
-                cq += (int)__popcll(__ballot(hit));
-                if (COUNT) { n_useful += (pb - jj) < 64u ? (pb - jj) : 64u; n_slots += 64; }
-                jj += 64;
+            if (long_sweep) {                              // (as above)
+                while (rr < DB_SEGS && cq < g.min_samples) {
+                    const uint32_t pb = sb[rr];
+                    if (jj >= pb) { ++rr; if (rr < DB_SEGS) jj = sa[rr]; continue; }
+                    float4 P[DB_AHEAD];
+#pragma unroll
+                    for (int u = 0; u < DB_AHEAD; ++u) {
+                        const uint32_t j = jj + 64u * u + l;
+                        P[u] = pts[j < pb ? j : pb - 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < DB_AHEAD; ++u) {
+                        const uint32_t jb = jj + 64u * u;
+                        const bool hit = jb + l < pb && db_within2(qp, P[u], g);
+                        cq += (int)__popcll(__ballot(hit));
+                        if (COUNT && jb < pb) { n_useful += (pb - jb) < 64u ? (pb - jb) : 64u; n_slots += 64; }
+                    }
+                    jj += 64u * DB_AHEAD;
+                }
+            } else {
+                while (rr < DB_SEGS && cq < g.min_samples) {
+                    const uint32_t pb = sb[rr];
+                    if (jj >= pb) { ++rr; if (rr < DB_SEGS) jj = sa[rr]; continue; }
+                    const uint32_t j = jj + l;
+                    bool hit = false;
+                    if (j < pb) hit = db_within2(qp, pts[j], g);
+                    cq += (int)__popcll(__ballot(hit));
+                    if (COUNT) { n_useful += (pb - jj) < 64u ? (pb - jj) : 64u; n_slots += 64; }
+                    jj += 64;
+                }
             }
             if (l == ql) count = cq;
         }
