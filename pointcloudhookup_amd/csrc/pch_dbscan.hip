@@ -753,7 +753,16 @@ __global__ __launch_bounds__(DB_THREADS) void db_rowtab_k(DbGrid g, const uint64
         const int xhi = (int)cx + 2 > g.mx ? g.mx : (int)cx + 2;
         const int c0 = (int)g.chunk_cells[chunk], c1 = (int)g.chunk_cells[chunk + 1];   // neighbours share the chunk
         v.x = c0 + db_lower(cell_key + c0, c1 - c0, db_pack(g, chunk, (uint64_t)nz, (uint64_t)ny, (uint64_t)xlo));
-        v.y = c0 + db_upper(cell_key + c0, c1 - c0, db_pack(g, chunk, (uint64_t)nz, (uint64_t)ny, (uint64_t)xhi));
+        // the end of the run: at most five cells (x - 2 .. x + 2) follow v.x, their keys ascending - five loads side by
+        // side instead of a second binary search (fourteen dependent loads in a chunk of 11 000 cells)
+        const uint64_t khi = db_pack(g, chunk, (uint64_t)nz, (uint64_t)ny, (uint64_t)xhi);
+        uint64_t kk[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) kk[i] = v.x + i < c1 ? cell_key[v.x + i] : ~0ull;
+        int cntx = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) cntx += kk[i] <= khi ? 1 : 0;
+        v.y = v.x + cntx;
     }
     rowtab[(int64_t)c * DB_ROWS + l] = v;
 }
